@@ -1,0 +1,78 @@
+"""ctypes binding of libppo_amd.so (the C ABI declared in include/ppo_amd.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  A missing
+library, a missing symbol or a missing GPU raises — loudly, at the call site.
+
+torch is imported before the library is opened so that the HIP runtime already
+mapped by PyTorch-ROCm (SONAME libamdhip64.so.7) is the one our kernels and
+streams live in; tensors' ``data_ptr()`` and ``torch.cuda.current_stream()``
+are then directly usable as the plain pointers / hipStream_t of the C ABI.
+"""
+import ctypes
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libppo_amd.so")
+
+PPO_TERM_NONE, PPO_TERM_U8, PPO_TERM_F32 = 0, 1, 2
+PPO_SCAN_AUTO, PPO_SCAN_COLUMNS, PPO_SCAN_TILES = 0, 1, 2
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_d = ctypes.c_double
+_f = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/ppo_amd.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it)
+SIGNATURES = {
+    "ppo_version": (_i, []),
+    "ppo_last_error": (ctypes.c_char_p, []),
+    "ppo_gae_scan_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i64, _d, _d, _d, _i, _vp]),
+    "ppo_bootstrapped_returns_f32": (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _i, _i, _i64, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class PpoAmdError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Open libppo_amd.so and type its entry points.  Raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PpoAmdError(
+                f"{LIB_PATH} is missing: build it with `python -m ppo_amd.build` "
+                "(hipcc, gfx950). There is no fallback path.")
+        import torch  # noqa: F401  (maps PyTorch-ROCm's HIP runtime first)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ppo_last_error()
+        raise PpoAmdError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise PpoAmdError("no HIP device visible: ppo_amd runs on MI355X only, there is no CPU path")
