@@ -161,10 +161,10 @@ def main():
         "dtype": "f64 carry / f32 io",
         "data": "synthetic",
         "config": {"workload": f"fused GAE+lambda-returns scan, N={N}, A={A} per GPU, bool terminals, "
-                               f"gamma={gamma} lambda={lam}", "regime": "columns" if A >= 32768 else "tiles"},
+                               f"gamma={gamma} lambda={lam}", "regime": "columns" if A > 65536 else "tiles"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "gae_columns_kernel" if A >= 32768 else "gae_tiles_kernel",
+                     "kernel": "gae_columns_kernel" if A > 65536 else "gae_tiles_kernel",
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "avg_kernel_ms": round(kern_avg_s * 1e3, 4)},
         "parity_bit_exact_vs_oracle": parity,

@@ -371,7 +371,9 @@ int launch_columns(const float *r, const float *v, const float *vf, const void *
                       (TERM == PPO_TERM_NONE || aligned(term, 4 * tsz));
     if (vec4) {
         const int packs = A / 4;
-        const int block = 256;
+        // one wave per workgroup: waves drift apart instead of marching through the rows in
+        // lockstep, which measured 5-10 % faster than 256-thread groups (tools/scan_tune.hip)
+        const int block = 64;
         const int grid = (packs + block - 1) / block;
         hipLaunchKernelGGL((gae_columns_kernel<TERM, 4, kColumnsU>), dim3(grid), dim3(block), 0, st, r,
                            v, vf, term, adv, ret, N, packs, ld, g32, gla, glr);
@@ -406,8 +408,9 @@ int launch_tiles(const float *r, const float *v, const float *vf, const void *te
     return launch_tiles_cb<TERM, 64>(r, v, vf, term, adv, ret, N, A, ld, g32, gla, glr, st);
 }
 
-// below this many columns the columns regime cannot put a wave on every SIMD
-constexpr int kTilesMaxA = 32768;
+// up to this many columns the tiles regime is faster (measured, tools/scan_sweep.py): the columns
+// regime needs A/256 >= ~1024 waves to cover the HBM latency-bandwidth product of 256 CUs
+constexpr int kTilesMaxA = 65536;
 
 }  // namespace
 }  // namespace ppo
@@ -427,7 +430,7 @@ extern "C" int ppo_gae_scan_f32(const float *rewards, const float *values, const
         if (!terminals) return fail(PPO_E_INVALID, "ppo_gae_scan_f32: terminals is null but terminal_kind=%d", terminal_kind);
     } else
         return fail(PPO_E_INVALID, "ppo_gae_scan_f32: unknown terminal_kind %d", terminal_kind);
-    if (regime == PPO_SCAN_AUTO) regime = (A >= kTilesMaxA) ? PPO_SCAN_COLUMNS : PPO_SCAN_TILES;
+    if (regime == PPO_SCAN_AUTO) regime = (A > kTilesMaxA) ? PPO_SCAN_COLUMNS : PPO_SCAN_TILES;
     if (regime != PPO_SCAN_COLUMNS && regime != PPO_SCAN_TILES)
         return fail(PPO_E_INVALID, "ppo_gae_scan_f32: unknown regime %d", regime);
 
