@@ -83,6 +83,116 @@ int ppo_bootstrapped_returns_f32(const float *rewards, const void *dones, int do
                                  const float *final_value, const float *gamma_arr, double gamma,
                                  float *out, int N, int A, int64_t ld, void *stream);
 
+/* ------------------------------------------------------------------------
+ * IMPALA-CNN building blocks (reference: rl/impala.py, rl/models.py:54-99).
+ * Activations are NCHW float32, contiguous.  Supported geometries: the layers
+ * of the (16, 32, 32)-channel IMPALA stacks on 84x84 (Atari) and 64x64
+ * (Procgen) observations; anything else returns PPO_E_INVALID.
+ * ---------------------------------------------------------------------- */
+
+/* input transform fused into the convolution's load */
+#define PPO_IN_NONE 0 /* float32 input used as is */
+#define PPO_IN_RELU 1 /* float32 input, max(x, 0) applied on load (pre-activation blocks, rl/impala.py:73-78) */
+#define PPO_IN_U8 2   /* uint8 observation, x / 255 applied on load (rl/models.py:842-848, "scaled") */
+
+/*
+ * out[n,o,y,x] = bias[o] + sum_{i,ky,kx} f(in[n,i,y+ky-1,x+kx-1]) * weight[o,i,ky,kx] (+ residual[n,o,y,x])
+ * 3x3, stride 1, zero padding 1 (torch.nn.Conv2d as used at rl/impala.py:61-62,96).
+ * weight: [cout, cin, 3, 3] (PyTorch layout).  bias, residual: nullable.
+ * FLOPs: 2*9*cin*cout*h*w per image, on the f32 MFMA.
+ */
+int ppo_conv3x3_forward_f32(const void *in, int in_mode, const float *weight, const float *bias,
+                            const float *residual, float *out, int n, int cin, int cout, int h, int w,
+                            void *stream);
+
+/*
+ * Gradient w.r.t. the convolution's (pre-transform) input:
+ *   dx[n,i,y,x] = (sum_{o,ky,kx} dy[n,o,y-ky+1,x-kx+1] * weight[o,i,ky,kx]) * [relu_src[n,i,y,x] > 0] + dres[n,i,y,x]
+ * relu_src (nullable): the pre-activation tensor the forward pass ReLU-ed on load.
+ * dres (nullable): gradient arriving over the residual skip connection.
+ * cin/cout are those of the FORWARD convolution.
+ */
+int ppo_conv3x3_backward_data_f32(const float *dy, const float *weight, const float *relu_src,
+                                  const float *dres, float *dx, int n, int cin, int cout, int h, int w,
+                                  void *stream);
+
+/*
+ * Weight and bias gradient of the same convolution (torch autograd of nn.Conv2d):
+ *   dweight[o,i,ky,kx] (+)= sum_{n,y,x} dy[n,o,y,x] * f(in[n,i,y+ky-1,x+kx-1])    dbias[o] (+)= sum dy[n,o,y,x]
+ * `in`/in_mode: the forward convolution's input and load transform.  workspace: scratch of at
+ * least ppo_conv3x3_wgrad_workspace_bytes(cin, cout) bytes (per-workgroup partial slabs, summed in
+ * a fixed order: deterministic).  accumulate != 0 adds into dweight/dbias (micro-batches,
+ * rl/rollout.py:2331-2374).  dbias nullable.
+ */
+size_t ppo_conv3x3_wgrad_workspace_bytes(int cin, int cout);
+int ppo_conv3x3_backward_weight_f32(const void *in, int in_mode, const float *dy, float *dweight, float *dbias,
+                                    void *workspace, size_t workspace_bytes, int n, int cin, int cout, int h,
+                                    int w, int accumulate, void *stream);
+
+/*
+ * 3x3 / stride 2 / pad 1 max pooling (F.max_pool2d, rl/impala.py:105): [n,c,h,w] -> [n,c,(h+1)/2,(w+1)/2].
+ * argmax (nullable uint8 [n,c,ho,wo]) records the winning window tap for the backward pass.
+ * Backward: din[n,c,h,w] = sum of dout over the windows whose argmax is this element.
+ */
+int ppo_maxpool3x3s2_forward_f32(const float *in, float *out, uint8_t *argmax, int n, int c, int h, int w,
+                                 void *stream);
+int ppo_maxpool3x3s2_backward_f32(const float *dout, const uint8_t *argmax, float *din, int n, int c, int h, int w,
+                                  void *stream);
+
+/*
+ * C[m,n] = epi( sum_k fa(A[m,k]) * fb(B[k,n]) + bias[n] ),  f32 MFMA.
+ * A element (m,k) at A[m*a_sm + k*a_sk]; B element (k,n) at B[k*b_sk + n*b_sn]; C row-major with ldc.
+ * relu_a / relu_b: apply max(.,0) to that operand on load.  bias [N], mask [M,ldc] nullable;
+ * mask gates the result: C = mask > 0 ? C : 0 (ReLU backward).  workspace (nullable): split-K
+ * scratch of ppo_gemm_workspace_bytes(M,N,K); without it the kernel runs unsplit.
+ * Replaces torch.nn.Linear forward/backward at rl/models.py:84,98,364-366,470-506.
+ */
+size_t ppo_gemm_workspace_bytes(int M, int N, int K);
+int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const float *B, int64_t b_sk, int64_t b_sn,
+                 int relu_b, const float *bias, const float *mask, float *C, int64_t ldc, int M, int N, int K,
+                 void *workspace, size_t workspace_bytes, void *stream);
+/* out[n] (+)= sum_m X[m*ldx + n]  (bias gradients) */
+int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *out, int accumulate, void *stream);
+
+/*
+ * Policy post-processing per sample row `heads[b, :]` = [logits(n_actions) | value heads | ...]:
+ * log_policy = log_softmax(logits / temperature) (rl/models.py:488) and an action:
+ *   greedy == 0: Gumbel-max  argmax_a(log_policy - log(-log u_a))  (rl/utils.py:248-256), with
+ *                u from `uniform` [B,n_actions] if given, else from a counter-based generator
+ *                keyed by (seed, offset + b*n_actions + a);
+ *   greedy != 0: argmax of the logits (rl/models.py:479, run_evaluation.py:621-623).
+ * Outputs (each nullable): log_policy [B,n_actions], actions [B] int32, log_pac [B] = log_policy[b, action].
+ */
+int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_actions, float temperature, const float *uniform,
+                       uint64_t seed, uint64_t offset, int greedy, float *log_policy, int32_t *actions,
+                       float *log_pac, void *stream);
+
+/*
+ * PPO minibatch loss, forward + gradient w.r.t. the head outputs
+ * (Runner.train_policy_minibatch / train_value_heads, rl/rollout.py:1596-1608,1610-1753):
+ *   gain_b = min(rho*A, clip(rho,1-eps,1+eps)*A) + ent_coef*H_b - sum_heads vf_coef*(V-R)^2
+ *   loss   = mean_b(-gain_b) * loss_scale          =>   grad_scale = loss_scale / B
+ * dheads [B,ldo] receives d loss / d heads (zeros in the columns past n_actions+n_value_heads).
+ * stats (nullable) [B,8]: loss_clip, entropy, value_loss, clipped(0/1), old_log_pac-log_pac,
+ * KL(new||old) term, gain, rho.  old_log_policy [B,n_actions] nullable (only for the KL statistic).
+ */
+int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_value_heads, const int32_t *actions,
+                     const float *old_log_pac, const float *old_log_policy, const float *advantages,
+                     const float *returns, float eps_clip, float ent_coef, float vf_coef, float grad_scale,
+                     float *dheads, float *stats, void *stream);
+
+/*
+ * One optimiser step on a flat parameter buffer: global-norm clip (clip_grad_norm_,
+ * rl/rollout.py:1309-1310; max_grad_norm <= 0 disables) then torch.optim.Adam's update
+ * (rl/rollout.py:126-141).  grads are divided by grad_div first (world size after an
+ * all-reduce SUM).  step >= 1 is the Adam step count AFTER this call.  workspace:
+ * ppo_adam_workspace_bytes() bytes.  grad_norm_out (nullable, device): the pre-clip norm.
+ */
+size_t ppo_adam_workspace_bytes(void);
+int ppo_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
+                      double lr, double beta1, double beta2, double eps, float max_grad_norm, float grad_div,
+                      void *workspace, float *grad_norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

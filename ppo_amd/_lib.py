@@ -17,12 +17,15 @@ LIB_PATH = os.path.join(HERE, "lib", "libppo_amd.so")
 
 PPO_TERM_NONE, PPO_TERM_U8, PPO_TERM_F32 = 0, 1, 2
 PPO_SCAN_AUTO, PPO_SCAN_COLUMNS, PPO_SCAN_TILES = 0, 1, 2
+PPO_IN_NONE, PPO_IN_RELU, PPO_IN_U8 = 0, 1, 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _i64 = ctypes.c_int64
 _d = ctypes.c_double
 _f = ctypes.c_float
+_sz = ctypes.c_size_t
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/ppo_amd.h declares
 # (tests/test_abi.py parses the header and checks this table and the .so against it)
@@ -31,6 +34,19 @@ SIGNATURES = {
     "ppo_last_error": (ctypes.c_char_p, []),
     "ppo_gae_scan_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i64, _d, _d, _d, _i, _vp]),
     "ppo_bootstrapped_returns_f32": (_i, [_vp, _vp, _i, _vp, _vp, _d, _vp, _i, _i, _i64, _vp]),
+    "ppo_conv3x3_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_backward_data_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i]),
+    "ppo_conv3x3_backward_weight_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
+    "ppo_maxpool3x3s2_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_maxpool3x3s2_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ppo_gemm_f32": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "ppo_colsum_f32": (_i, [_vp, _i, _i, _i64, _vp, _i, _vp]),
+    "ppo_policy_act_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp]),
+    "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "ppo_adam_workspace_bytes": (_sz, []),
+    "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,183 @@
+// Policy-head post-processing for the discrete-action PPO path (gfx950).  All of it is
+// tiny per-sample work (n_actions <= 32): one thread per sample, fully fused, no host
+// round trip (the reference syncs device->host 5 times per env step, rl/rollout.py:641,
+// 809-813).
+//
+//  * ppo_policy_act_f32   log_softmax of the policy logits (rl/models.py:488), then either
+//                         Gumbel-max sampling  argmax(logp - log(-log u))  (rl/utils.py:248-256)
+//                         or the greedy argmax (rl/models.py:475-485, temperature 0).
+//  * ppo_ppo_loss_f32     clipped-surrogate + entropy + value loss of
+//                         Runner.train_policy_minibatch (rl/rollout.py:1640-1660,1682,1744-1753,
+//                         1596-1608), forward AND the gradient w.r.t. the head outputs, plus the
+//                         per-sample statistics the reference logs.
+//
+// Head outputs arrive as one row per sample: [ policy logits (n_actions) | value heads (vh) | ... ],
+// leading dimension ldo; columns past n_actions + vh get zero gradient (the reference's
+// advantage head is evaluated but never enters the loss, rl/models.py:506).
+#include "common.h"
+
+namespace ppo {
+namespace {
+
+constexpr int kMaxActions = 32;
+
+// counter-based uniform in (0, 1): 2 rounds of a 64-bit mix (splitmix64 finaliser) of
+// (seed, counter); 24 mantissa bits, never 0 or 1 so that log(-log u) is finite.
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict__ heads, int B, int ldo, int nA,
+                                                        float temperature, const float *__restrict__ uniform,
+                                                        uint64_t seed, uint64_t offset, int greedy,
+                                                        float *__restrict__ log_policy, int32_t *__restrict__ actions,
+                                                        float *__restrict__ log_pac)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *z = heads + (size_t)b * ldo;
+    float logits[kMaxActions];
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int a = 0; a < nA; ++a) {
+        logits[a] = z[a] / temperature;
+        mx = fmaxf(mx, logits[a]);
+    }
+    float se = 0.f;
+    for (int a = 0; a < nA; ++a) se += expf(logits[a] - mx);
+    const float lse = mx + logf(se);
+    int best = 0;
+    float best_score = -INFINITY;
+    for (int a = 0; a < nA; ++a) {
+        const float lp = logits[a] - lse;
+        logits[a] = lp;
+        if (log_policy) log_policy[(size_t)b * nA + a] = lp;
+        float score;
+        if (greedy) {
+            score = z[a];  // argmax of the unscaled logits (rl/models.py:479)
+        } else {
+            const float u = uniform ? uniform[(size_t)b * nA + a] : uniform01(seed, offset + (uint64_t)b * nA + a);
+            score = lp - logf(-logf(u));
+        }
+        if (score > best_score) {  // first maximum wins, as np.argmax / torch.argmax
+            best_score = score;
+            best = a;
+        }
+    }
+    if (actions) actions[b] = best;
+    if (log_pac) log_pac[b] = logits[best];
+}
+
+// statistics row per sample (reduced on demand by the host side, one D2H per iteration)
+enum { ST_LOSS_CLIP = 0, ST_ENTROPY, ST_VALUE_LOSS, ST_CLIPPED, ST_KL_APPROX, ST_KL_TRUE, ST_GAIN, ST_RATIO, ST_N };
+
+__global__ __launch_bounds__(64) void ppo_loss_kernel(
+    const float *__restrict__ heads, int B, int ldo, int nA, int vh, const int32_t *__restrict__ actions,
+    const float *__restrict__ old_log_pac, const float *__restrict__ old_log_policy,
+    const float *__restrict__ advantages, const float *__restrict__ returns, float eps_clip, float ent_coef,
+    float vf_coef, float grad_scale, float *__restrict__ dheads, float *__restrict__ stats)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *z = heads + (size_t)b * ldo;
+    float lp[kMaxActions];
+    float mx = -INFINITY;
+    for (int a = 0; a < nA; ++a) {
+        lp[a] = z[a];
+        mx = fmaxf(mx, lp[a]);
+    }
+    float se = 0.f;
+    for (int a = 0; a < nA; ++a) se += expf(lp[a] - mx);
+    const float lse = mx + logf(se);
+    float entropy = 0.f, kl_true = 0.f;
+    for (int a = 0; a < nA; ++a) {
+        lp[a] -= lse;
+        const float p = expf(lp[a]);
+        entropy -= p * lp[a];
+        if (old_log_policy) kl_true += p * (lp[a] - old_log_policy[(size_t)b * nA + a]);
+    }
+    const int act = actions[b];
+    const float adv = advantages[b];
+    const float logpac = lp[act];
+    const float ratio = expf(logpac - old_log_pac[b]);
+    const float clipped_ratio = fminf(fmaxf(ratio, 1.f - eps_clip), 1.f + eps_clip);
+    const float s1 = ratio * adv, s2 = clipped_ratio * adv;
+    const float loss_clip = fminf(s1, s2);
+    // d loss_clip / d ratio, with torch.min's tie rule (half to each side) and clamp's
+    // pass-through inside [1-eps, 1+eps]:  inside -> adv; outside -> adv only if s1 < s2
+    const bool inside = ratio >= 1.f - eps_clip && ratio <= 1.f + eps_clip;
+    float dclip_dratio;
+    if (inside) dclip_dratio = adv;
+    else dclip_dratio = s1 < s2 ? adv : (s1 == s2 ? 0.5f * adv : 0.f);
+
+    // value heads: vf_coef * (V - R)^2 per head (rl/rollout.py:1596-1608)
+    float vloss = 0.f;
+    float *dz = dheads + (size_t)b * ldo;
+    for (int i = 0; i < vh; ++i) {
+        const float diff = z[nA + i] - returns[(size_t)b * vh + i];
+        vloss += vf_coef * diff * diff;
+        dz[nA + i] = grad_scale * 2.f * vf_coef * diff;  // d(-gain)/dV
+    }
+    for (int i = nA + vh; i < ldo; ++i) dz[i] = 0.f;
+
+    // d(-gain)/dlogit_j = -[ dclip_dratio * ratio * (1{j=act} - p_j) + ent_coef * (-p_j (logp_j + H)) ]
+    const float w = dclip_dratio * ratio;
+    for (int a = 0; a < nA; ++a) {
+        const float p = expf(lp[a]);
+        const float dpg = w * ((a == act ? 1.f : 0.f) - p);
+        const float dent = -p * (lp[a] + entropy);
+        dz[a] = -grad_scale * (dpg + ent_coef * dent);
+    }
+    if (stats) {
+        float *s = stats + (size_t)b * ST_N;
+        s[ST_LOSS_CLIP] = loss_clip;
+        s[ST_ENTROPY] = entropy;
+        s[ST_VALUE_LOSS] = vloss;
+        s[ST_CLIPPED] = fabsf(ratio - 1.f) > eps_clip ? 1.f : 0.f;
+        s[ST_KL_APPROX] = old_log_pac[b] - logpac;
+        s[ST_KL_TRUE] = kl_true;
+        s[ST_GAIN] = loss_clip + ent_coef * entropy - vloss;
+        s[ST_RATIO] = ratio;
+    }
+}
+
+}  // namespace
+}  // namespace ppo
+
+extern "C" int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_actions, float temperature,
+                                  const float *uniform, uint64_t seed, uint64_t offset, int greedy, float *log_policy,
+                                  int32_t *actions, float *log_pac, void *stream)
+{
+    using namespace ppo;
+    if (B < 0 || n_actions <= 0 || n_actions > kMaxActions || ldo < n_actions)
+        return fail(PPO_E_INVALID, "ppo_policy_act_f32: bad shape (B=%d n_actions=%d ldo=%d, max %d actions)", B,
+                    n_actions, ldo, kMaxActions);
+    if (B == 0) return PPO_OK;
+    if (!heads) return fail(PPO_E_INVALID, "ppo_policy_act_f32: null heads");
+    if (!(temperature > 0.f)) return fail(PPO_E_INVALID, "ppo_policy_act_f32: temperature must be > 0 (use greedy=1 for argmax)");
+    hipLaunchKernelGGL(policy_act_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,
+                       n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac);
+    return check_launch("policy_act_kernel");
+}
+
+extern "C" int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_value_heads,
+                                const int32_t *actions, const float *old_log_pac, const float *old_log_policy,
+                                const float *advantages, const float *returns, float eps_clip, float ent_coef,
+                                float vf_coef, float grad_scale, float *dheads, float *stats, void *stream)
+{
+    using namespace ppo;
+    if (B < 0 || n_actions <= 0 || n_actions > kMaxActions || n_value_heads < 0 || ldo < n_actions + n_value_heads)
+        return fail(PPO_E_INVALID, "ppo_ppo_loss_f32: bad shape");
+    if (B == 0) return PPO_OK;
+    if (!heads || !actions || !old_log_pac || !advantages || !dheads || (n_value_heads > 0 && !returns))
+        return fail(PPO_E_INVALID, "ppo_ppo_loss_f32: null pointer");
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo, n_actions,
+                       n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns, eps_clip, ent_coef,
+                       vf_coef, grad_scale, dheads, stats);
+    return check_launch("ppo_loss_kernel");
+}

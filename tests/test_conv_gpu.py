@@ -1,0 +1,109 @@
+"""GPU: hand-written MFMA conv3x3 (forward, backward-data) against torch's fp32 conv2d.
+
+The reference runs these contractions through torch.nn.Conv2d (rl/impala.py:61-62,96);
+summation order differs between any two implementations, so the bar is the fp32
+tolerance SURVEY.md §8d gives for conv results: rel 1e-4 of the tensor's max.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+from ppo_amd import _lib  # noqa: E402
+
+GEOMS = [(4, 16, 84), (5, 16, 84), (3, 16, 64), (16, 16, 42), (16, 32, 42), (32, 32, 21), (32, 32, 11),
+         (16, 16, 32), (16, 32, 32), (32, 32, 16), (32, 32, 8)]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _close(a, b, rel=1e-4):
+    return (a.double() - b.double()).abs().max().item() <= rel * max(b.abs().max().item(), 1e-30)
+
+
+def conv_fwd(x, w, b, res, mode):
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    out = torch.empty((n, cout, h, wd), dtype=torch.float32, device=x.device)
+    rc = _lib.load().ppo_conv3x3_forward_f32(_p(x), mode, _p(w), _p(b), _p(res), _p(out), n, cin, cout, h, wd,
+                                             _lib.current_stream())
+    _lib.check(rc, "ppo_conv3x3_forward_f32")
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,hw", GEOMS)
+@pytest.mark.parametrize("n", [1, 3, 37])
+def test_forward_matches_torch(cin, cout, hw, n):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(cin * 1000 + cout * 10 + hw + n)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.2).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    if cin <= 5:
+        xu = torch.randint(0, 256, (n, cin, hw, hw), generator=g, dtype=torch.uint8).to(dev)
+        out = conv_fwd(xu, w, b, None, _lib.PPO_IN_U8)
+        ref = F.conv2d(xu.float() / 255.0, w, b, padding=1)
+        assert _close(out, ref)
+        xf = torch.randn(n, cin, hw, hw, generator=g).to(dev)
+        assert _close(conv_fwd(xf, w, b, None, _lib.PPO_IN_NONE), F.conv2d(xf, w, b, padding=1))
+    else:
+        x = torch.randn(n, cin, hw, hw, generator=g).to(dev)
+        res = torch.randn(n, cout, hw, hw, generator=g).to(dev)
+        assert _close(conv_fwd(x, w, b, None, _lib.PPO_IN_NONE), F.conv2d(x, w, b, padding=1))
+        if cin == cout:
+            out = conv_fwd(x, w, b, res, _lib.PPO_IN_RELU)
+            assert _close(out, F.conv2d(F.relu(x), w, b, padding=1) + res)
+            assert _close(conv_fwd(x, w, None, None, _lib.PPO_IN_RELU), F.conv2d(F.relu(x), w, None, padding=1))
+
+
+def test_forward_exact_on_integer_data():
+    """Small-integer operands make every product and partial sum exact in fp32, so any
+    operand-mapping mistake (wrong lane->element map, swapped taps) shows as a hard mismatch."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for cin, cout, hw in [(16, 32, 42), (32, 32, 11), (16, 16, 42)]:
+        x = torch.randint(-3, 4, (5, cin, hw, hw), generator=g).float().to(dev)
+        w = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float().to(dev)
+        b = torch.randint(-5, 6, (cout,), generator=g).float().to(dev)
+        assert torch.equal(conv_fwd(x, w, b, None, _lib.PPO_IN_NONE), F.conv2d(x, w, b, padding=1))
+
+
+@pytest.mark.parametrize("cin,cout,hw", [g for g in GEOMS if g[0] > 5])
+def test_backward_data_matches_autograd(cin, cout, hw):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + hw)
+    n = 9
+    pre = torch.randn(n, cin, hw, hw, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.2).to(dev)
+    dy = torch.randn(n, cout, hw, hw, generator=g).to(dev)
+    dres = torch.randn(n, cin, hw, hw, generator=g).to(dev)
+    lib = _lib.load()
+
+    # plain: dx = conv_transpose(dy)
+    y = F.conv2d(pre, w, None, padding=1)
+    (ref,) = torch.autograd.grad(y, pre, dy)
+    dx = torch.empty_like(ref)
+    rc = lib.ppo_conv3x3_backward_data_f32(_p(dy), _p(w), None, None, _p(dx), n, cin, cout, hw, hw, _lib.current_stream())
+    _lib.check(rc, "bwd")
+    assert _close(dx, ref)
+
+    # with the ReLU mask of the forward's load transform and a skip-connection gradient
+    y = F.conv2d(F.relu(pre), w, None, padding=1)
+    (ref,) = torch.autograd.grad(y, pre, dy)
+    ref = ref + dres
+    rc = lib.ppo_conv3x3_backward_data_f32(_p(dy), _p(w), _p(pre), _p(dres), _p(dx), n, cin, cout, hw, hw,
+                                           _lib.current_stream())
+    _lib.check(rc, "bwd")
+    assert _close(dx, ref)
+
+
+def test_unsupported_geometry_is_an_error():
+    dev = torch.device("cuda")
+    x = torch.zeros(1, 7, 10, 10, device=dev)
+    w = torch.zeros(8, 7, 3, 3, device=dev)
+    out = torch.zeros(1, 8, 10, 10, device=dev)
+    rc = _lib.load().ppo_conv3x3_forward_f32(_p(x), 0, _p(w), None, None, _p(out), 1, 7, 8, 10, 10, _lib.current_stream())
+    assert rc == -1

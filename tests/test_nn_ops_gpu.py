@@ -1,0 +1,311 @@
+"""GPU: conv weight-gradient, max-pool, GEMM, policy/loss and Adam kernels against plain
+PyTorch fp32 (autograd / torch.optim.Adam), the ops the reference gets from torch at
+rl/impala.py:61-62,96,105, rl/models.py:84,364-366,488 and rl/rollout.py:126-141,1309-1310,1640-1753.
+Tolerances: 1e-4 of the tensor's max for contractions (summation order differs), 1e-5 for
+elementwise ops, exact for integer outputs (argmax, actions).
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+from ppo_amd import _lib  # noqa: E402
+
+DEV = "cuda"
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _close(a, b, rel=1e-4):
+    return (a.double() - b.double()).abs().max().item() <= rel * max(b.abs().max().item(), 1e-30)
+
+
+def _st():
+    return _lib.current_stream()
+
+
+# ------------------------------------------------------------------ conv weight gradient
+WG = [(4, 16, 84, "u8"), (4, 16, 84, "none"), (5, 16, 84, "u8"), (3, 16, 64, "u8"), (16, 16, 42, "relu"),
+      (16, 32, 42, "none"), (32, 32, 21, "relu"), (32, 32, 21, "none"), (32, 32, 11, "relu"), (16, 16, 32, "relu"),
+      (16, 32, 32, "none"), (32, 32, 16, "relu"), (32, 32, 16, "none"), (32, 32, 8, "relu")]
+MODE = {"none": 0, "relu": 1, "u8": 2}
+
+
+@pytest.mark.parametrize("cin,cout,hw,mode", WG)
+@pytest.mark.parametrize("n", [2, 41, 300])
+def test_conv_weight_grad(cin, cout, hw, mode, n):
+    if n == 300 and hw >= 64:
+        n = 70
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin * 7 + cout + hw + n)
+    if mode == "u8":
+        x = torch.randint(0, 256, (n, cin, hw, hw), generator=g, dtype=torch.uint8).to(DEV)
+        xin = x.float() / 255.0
+    else:
+        x = torch.randn(n, cin, hw, hw, generator=g).to(DEV)
+        xin = F.relu(x) if mode == "relu" else x
+    dy = torch.randn(n, cout, hw, hw, generator=g).to(DEV)
+    w = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    b = torch.zeros(cout, device=DEV, requires_grad=True)
+    y = F.conv2d(xin, w, b, padding=1)
+    rw, rb = torch.autograd.grad(y, (w, b), dy)
+    ws_bytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
+    ws = torch.empty(ws_bytes // 4, device=DEV)
+    dw = torch.full((cout, cin, 3, 3), 7.0, device=DEV)
+    db = torch.full((cout,), 7.0, device=DEV)
+    rc = lib.ppo_conv3x3_backward_weight_f32(_p(x), MODE[mode], _p(dy), _p(dw), _p(db), _p(ws), ws_bytes, n, cin, cout,
+                                             hw, hw, 0, _st())
+    _lib.check(rc, "wgrad")
+    assert _close(dw, rw) and _close(db, rb)
+    # accumulate: second call adds
+    rc = lib.ppo_conv3x3_backward_weight_f32(_p(x), MODE[mode], _p(dy), _p(dw), _p(db), _p(ws), ws_bytes, n, cin, cout,
+                                             hw, hw, 1, _st())
+    _lib.check(rc, "wgrad")
+    assert _close(dw, 2 * rw) and _close(db, 2 * rb)
+
+
+def test_conv_weight_grad_exact_on_integers():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    n, cin, cout, hw = 6, 16, 32, 42
+    x = torch.randint(-2, 3, (n, cin, hw, hw), generator=g).float().to(DEV)
+    dy = torch.randint(-2, 3, (n, cout, hw, hw), generator=g).float().to(DEV)
+    w = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
+    rw, = torch.autograd.grad(F.conv2d(x, w, None, padding=1), (w,), dy)
+    ws_bytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
+    ws = torch.empty(ws_bytes // 4, device=DEV)
+    dw = torch.empty_like(rw)
+    db = torch.empty(cout, device=DEV)
+    _lib.check(lib.ppo_conv3x3_backward_weight_f32(_p(x), 0, _p(dy), _p(dw), _p(db), _p(ws), ws_bytes, n, cin, cout,
+                                                   hw, hw, 0, _st()), "wgrad")
+    assert torch.equal(dw, rw)
+    assert torch.equal(db, dy.sum(dim=(0, 2, 3)))
+
+
+# ------------------------------------------------------------------ max pool
+@pytest.mark.parametrize("c,hw", [(16, 84), (32, 42), (32, 21), (16, 64), (32, 32), (32, 16), (3, 7), (2, 1)])
+def test_maxpool_forward_backward(c, hw):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(c + hw)
+    n = 5
+    x = torch.randn(n, c, hw, hw, generator=g).to(DEV).requires_grad_(True)
+    ref = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    ho = (hw + 1) // 2
+    assert ref.shape[-1] == ho
+    out = torch.empty_like(ref)
+    arg = torch.empty(ref.shape, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ppo_maxpool3x3s2_forward_f32(_p(x), _p(out), _p(arg), n, c, hw, hw, _st()), "pool")
+    assert torch.equal(out, ref)
+    dout = torch.randn(ref.shape, generator=g).to(DEV)
+    (rdx,) = torch.autograd.grad(ref, x, dout)
+    dx = torch.empty_like(rdx)
+    _lib.check(lib.ppo_maxpool3x3s2_backward_f32(_p(dout), _p(arg), _p(dx), n, c, hw, hw, _st()), "pool bwd")
+    assert _close(dx, rdx, 1e-6)
+
+
+def test_maxpool_ties_route_to_first_tap_like_torch():
+    lib = _lib.load()
+    x = torch.zeros(1, 1, 6, 6, device=DEV, requires_grad=True)  # every window is a tie
+    ref = F.max_pool2d(x, 3, 2, 1)
+    dout = torch.arange(1, 10, dtype=torch.float32, device=DEV).reshape(1, 1, 3, 3)
+    (rdx,) = torch.autograd.grad(ref, x, dout)
+    out = torch.empty_like(ref)
+    arg = torch.empty(ref.shape, dtype=torch.uint8, device=DEV)
+    dx = torch.empty_like(rdx)
+    _lib.check(lib.ppo_maxpool3x3s2_forward_f32(_p(x), _p(out), _p(arg), 1, 1, 6, 6, _st()), "pool")
+    _lib.check(lib.ppo_maxpool3x3s2_backward_f32(_p(dout), _p(arg), _p(dx), 1, 1, 6, 6, _st()), "pool bwd")
+    assert torch.equal(dx, rdx)
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(A, a_sm, a_sk, relu_a, B, b_sk, b_sn, relu_b, bias, mask, M, N, K, use_ws=True):
+    lib = _lib.load()
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ws_bytes = lib.ppo_gemm_workspace_bytes(M, N, K) if use_ws else 0
+    ws = torch.empty(max(ws_bytes // 4, 1), device=DEV)
+    rc = lib.ppo_gemm_f32(_p(A), a_sm, a_sk, relu_a, _p(B), b_sk, b_sn, relu_b, _p(bias), _p(mask), _p(C), N, M, N, K,
+                          _p(ws) if use_ws else None, ws_bytes, _st())
+    _lib.check(rc, "gemm")
+    return C
+
+
+@pytest.mark.parametrize("bsz", [1, 7, 256, 300])
+def test_gemm_dense_layer_forms(bsz):
+    g = torch.Generator().manual_seed(bsz)
+    K, H = 3872, 256
+    flat = torch.randn(bsz, K, generator=g).to(DEV)
+    W = (torch.randn(H, K, generator=g) * 0.02).to(DEV)
+    b = torch.randn(H, generator=g).to(DEV)
+    # forward: h = relu(flat) @ W^T + b      (A k-contiguous, B k-contiguous, split-K)
+    h = gemm(flat, K, 1, 1, W, 1, K, 0, b, None, bsz, H, K)
+    ref = F.linear(F.relu(flat), W, b)
+    assert _close(h, ref)
+    assert _close(gemm(flat, K, 1, 1, W, 1, K, 0, b, None, bsz, H, K, use_ws=False), ref)
+    dh = torch.randn(bsz, H, generator=g).to(DEV)
+    # input gradient with ReLU gate: dflat = (dh @ W) * (flat > 0)
+    dflat = gemm(dh, H, 1, 0, W, K, 1, 0, None, flat, bsz, K, H)
+    assert _close(dflat, (dh @ W) * (flat > 0))
+    # weight gradient: dW = dh^T @ relu(flat)
+    dW = gemm(dh, 1, H, 0, flat, K, 1, 1, None, None, H, K, bsz)
+    assert _close(dW, dh.t() @ F.relu(flat))
+
+
+def test_gemm_heads_forms_and_colsum():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    bsz, H, NH = 256, 256, 13
+    h = torch.randn(bsz, H, generator=g).to(DEV)
+    Wh = torch.randn(NH, H, generator=g).to(DEV)
+    bh = torch.randn(NH, generator=g).to(DEV)
+    o = gemm(h, H, 1, 1, Wh, 1, H, 0, bh, None, bsz, NH, H)
+    assert _close(o, F.linear(F.relu(h), Wh, bh))
+    do = torch.randn(bsz, NH, generator=g).to(DEV)
+    assert _close(gemm(do, 1, NH, 0, h, H, 1, 1, None, None, NH, H, bsz), do.t() @ F.relu(h))
+    assert _close(gemm(do, NH, 1, 0, Wh, H, 1, 0, None, h, bsz, H, NH), (do @ Wh) * (h > 0))
+    out = torch.zeros(NH, device=DEV)
+    _lib.check(lib.ppo_colsum_f32(_p(do), bsz, NH, NH, _p(out), 0, _st()), "colsum")
+    assert _close(out, do.sum(0), 1e-5)
+    _lib.check(lib.ppo_colsum_f32(_p(do), bsz, NH, NH, _p(out), 1, _st()), "colsum")
+    assert _close(out, 2 * do.sum(0), 1e-5)
+
+
+def test_gemm_exact_on_integers_asymmetric():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 70, 45, 37
+    A = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
+    B = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)
+    assert torch.equal(gemm(A, K, 1, 0, B, N, 1, 0, None, None, M, N, K), A @ B)
+    At = A.t().contiguous()  # stored [K, M]
+    assert torch.equal(gemm(At, 1, M, 0, B, N, 1, 0, None, None, M, N, K), A @ B)
+
+
+# ------------------------------------------------------------------ policy act / PPO loss
+@pytest.mark.parametrize("nA", [2, 6, 15, 18])
+def test_policy_act_log_softmax_gumbel_and_greedy(nA):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nA)
+    B, ldo = 300, 2 * nA + 1
+    heads = torch.randn(B, ldo, generator=g).to(DEV)
+    u = torch.rand(B, nA, generator=g).clamp_(1e-6, 1 - 1e-6).to(DEV)
+    lp = torch.empty(B, nA, device=DEV)
+    act = torch.empty(B, dtype=torch.int32, device=DEV)
+    lpa = torch.empty(B, device=DEV)
+    _lib.check(lib.ppo_policy_act_f32(_p(heads), B, ldo, nA, 1.0, _p(u), 0, 0, 0, _p(lp), _p(act), _p(lpa), _st()), "act")
+    ref_lp = F.log_softmax(heads[:, :nA], dim=1)
+    assert _close(lp, ref_lp, 1e-5)
+    scores = ref_lp - torch.log(-torch.log(u))
+    top2 = scores.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4  # exclude near-ties (fp reassociation of log-sum-exp)
+    assert clear.sum() > B * 0.9
+    assert torch.equal(act[clear].long(), scores.argmax(1)[clear])
+    assert _close(lpa, ref_lp.gather(1, act.long()[:, None])[:, 0], 1e-5)
+    # greedy: exact argmax of the raw logits, first index on ties
+    heads[0, :nA] = 1.0
+    _lib.check(lib.ppo_policy_act_f32(_p(heads), B, ldo, nA, 1.0, None, 0, 0, 1, None, _p(act), None, _st()), "act")
+    assert torch.equal(act.long(), heads[:, :nA].argmax(1))
+    assert act[0].item() == 0
+    # internal generator: actions follow the policy distribution (chi-square-ish sanity), seeds differ
+    hb = torch.zeros(20000, ldo, device=DEV)
+    hb[:, :nA] = torch.linspace(0, 1.5, nA, device=DEV)
+    a1 = torch.empty(20000, dtype=torch.int32, device=DEV)
+    a2 = torch.empty_like(a1)
+    _lib.check(lib.ppo_policy_act_f32(_p(hb), 20000, ldo, nA, 1.0, None, 123, 0, 0, None, _p(a1), None, _st()), "act")
+    _lib.check(lib.ppo_policy_act_f32(_p(hb), 20000, ldo, nA, 1.0, None, 124, 0, 0, None, _p(a2), None, _st()), "act")
+    freq = torch.bincount(a1.long(), minlength=nA).float() / 20000
+    p = F.softmax(hb[0, :nA], dim=0)
+    assert (freq - p).abs().max().item() < 0.02
+    assert not torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("nA", [4, 6, 15])
+def test_ppo_loss_matches_reference_formula_autograd(nA):
+    """The loss exactly as written in rl/rollout.py:1640-1660,1682,1744-1753,1596-1608, via autograd."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nA * 3)
+    B, vh = 256, 1
+    ldo = 2 * nA + vh
+    eps, ent, vfc, loss_scale = 0.2, 0.01, 0.5, 0.5
+    heads = (torch.randn(B, ldo, generator=g) * 1.5).to(DEV).requires_grad_(True)
+    actions = torch.randint(0, nA, (B,), generator=g).to(DEV)
+    old_lp = F.log_softmax(torch.randn(B, nA, generator=g) * 1.5, dim=1).to(DEV)
+    old_log_pac = old_lp.gather(1, actions[:, None])[:, 0] + (torch.randn(B, generator=g) * 0.3).to(DEV)
+    adv = torch.randn(B, generator=g).to(DEV)
+    adv[:5] = 0.0
+    ret = torch.randn(B, vh, generator=g).to(DEV)
+
+    logps = F.log_softmax(heads[:, :nA], dim=1)
+    logpac = logps[range(B), actions]
+    ratio = torch.exp(logpac - old_log_pac)
+    clipped = torch.clamp(ratio, 1 - eps, 1 + eps)
+    loss_clip = torch.min(ratio * adv, clipped * adv)
+    entropy = -(logps.exp() * logps).sum(-1)
+    vloss = vfc * torch.square(heads[:, nA] - ret[:, 0])
+    gain = loss_clip + entropy * ent - vloss
+    loss = (-gain) * loss_scale
+    loss.mean().backward()
+
+    dh = torch.full((B, ldo), float("nan"), device=DEV)
+    stats = torch.empty(B, 8, device=DEV)
+    rc = lib.ppo_ppo_loss_f32(_p(heads), B, ldo, nA, vh, _p(actions.int()), _p(old_log_pac), _p(old_lp), _p(adv),
+                              _p(ret), eps, ent, vfc, loss_scale / B, _p(dh), _p(stats), _st())
+    _lib.check(rc, "loss")
+    assert (dh - heads.grad).abs().max().item() <= 1e-5 * heads.grad.abs().max().item() + 1e-9
+    assert _close(stats[:, 0], loss_clip.detach(), 1e-5)
+    assert _close(stats[:, 1], entropy.detach(), 1e-5)
+    assert _close(stats[:, 2], vloss.detach(), 1e-5)
+    assert torch.equal(stats[:, 3], (torch.abs(ratio - 1.0) > eps).float())
+    assert _close(stats[:, 4], (old_log_pac - logpac).detach(), 1e-5)
+    kl = F.kl_div(old_lp, logps.detach(), log_target=True, reduction="none").sum(-1)
+    assert (stats[:, 5] - kl).abs().max().item() < 1e-5
+    assert _close(stats[:, 6], gain.detach(), 1e-5)
+
+
+# ------------------------------------------------------------------ Adam + global-norm clip
+@pytest.mark.parametrize("n,max_norm", [(1000, 20.0), (1092579, 20.0), (1092579, 0.5), (333, 0.0)])
+def test_adam_with_global_norm_clip_matches_torch(n, max_norm):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n)
+    p_ref = torch.nn.Parameter(torch.randn(n, generator=g).to(DEV))
+    opt = torch.optim.Adam([p_ref], lr=2.5e-4, eps=1e-5, betas=(0.9, 0.999))
+    w = p_ref.detach().clone()
+    m = torch.zeros_like(w)
+    v = torch.zeros_like(w)
+    ws = torch.empty(lib.ppo_adam_workspace_bytes() // 4, device=DEV)
+    norm = torch.zeros(1, device=DEV)
+    for step in range(1, 6):
+        grad = (torch.randn(n, generator=g) * (0.05 * step)).to(DEV)
+        p_ref.grad = grad.clone()
+        ref_norm = grad.norm(2)
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([p_ref], max_norm)
+        opt.step()
+        rc = lib.ppo_adam_step_f32(_p(w), _p(grad), _p(m), _p(v), n, step, 2.5e-4, 0.9, 0.999, 1e-5, max_norm, 1.0,
+                                   _p(ws), _p(norm), _st())
+        _lib.check(rc, "adam")
+        assert abs(norm.item() - ref_norm.item()) <= 1e-5 * ref_norm.item()
+        assert (w - p_ref.detach()).abs().max().item() <= 2e-6 * max(1.0, p_ref.detach().abs().max().item())
+    st = opt.state[p_ref]
+    assert _close(m, st["exp_avg"], 1e-5) and _close(v, st["exp_avg_sq"], 1e-5)
+
+
+def test_adam_grad_div_equals_prescaled_gradients():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    n = 5000
+    w0 = torch.randn(n, generator=g).to(DEV)
+    grad = torch.randn(n, generator=g).to(DEV)
+    ws = torch.empty(lib.ppo_adam_workspace_bytes() // 4, device=DEV)
+    outs = []
+    for gsc, div in ((1.0, 1.0), (8.0, 8.0)):
+        w, m, v = w0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        gg = grad * gsc
+        _lib.check(lib.ppo_adam_step_f32(_p(w), _p(gg), _p(m), _p(v), n, 1, 2.5e-4, 0.9, 0.999, 1e-5, 0.5, div, _p(ws),
+                                         None, _st()), "adam")
+        outs.append(w)
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-7
