@@ -3,10 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (for N>1 launched by torch.distributed.run; RCCL only for
-the barrier and the max-over-ranks time: env columns are independent, so the
-data path has no collective — "scaling": "weak").  Prints ONE JSON line on
-rank 0.  See DESIGN.md §Measurement for how every figure is defined.
+A "step" is ONE PPO iteration of BASELINE.json's config 2 on synthetic data: 256 envs per GPU x 256
+steps of 84x84x4 uint8 observations (rollout with the policy forward + on-device sampling), the fused
+GAE/lambda-return scan, and 2 policy epochs of 256-sample minibatches (forward, PPO loss, backward,
+global-norm clip, Adam) through the hand-written HIP IMPALA network.  value = env-steps/s summed over
+ranks (the reference's IPS, rl/ppo.py:354-365).  One process per GPU; for N > 1 the envs are sharded
+(weak scaling: 256 envs per rank, global minibatch 256*N so the optimiser-step count is unchanged)
+and the only collectives are the RCCL gradient all-reduce per optimiser step and the advantage
+moments per batch.
+
+Also reported on the same JSON line:
+  roofline      the kernel with the largest share of the step (a conv weight-gradient launch), timed
+                live with HIP events on the launch stream during the timed region, against the fp32
+                MFMA peak;
+  gae_scan      the fused GAE scan at the bandwidth-regime size (N=256, A=2^20) against HBM peak, and
+                its latency at the config size;
+  cpu_baseline  the same PPO iteration through oracle/model_torch.py (plain torch CPU operators — what
+                the reference runs with --device=cpu) on a bounded sample, extrapolated to env-steps/s.
 """
 import argparse
 import json
@@ -20,22 +33,26 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
-BYTES_PER_ELEM = 17     # fused adv+returns scan: read r4+v4+done1, write adv4+ret4
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_* dense peak (MI355X_MICROARCH.md, Matrix cores)
+SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write adv4+ret4
+FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--scan-envs", type=int, default=1 << 20, help="A of the bandwidth-regime scan")
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--agents", type=int, default=256, help="envs per GPU")
     p.add_argument("--n-steps", type=int, default=256, help="rollout length N")
+    p.add_argument("--scan-envs", type=int, default=1 << 20, help="A of the bandwidth-regime scan")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-scan", action="store_true")
     return p.parse_args()
 
 
-def init_dist(args):
+def init_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -43,139 +60,241 @@ def init_dist(args):
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local)
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     return world, rank, local
 
 
 def barrier(world):
     if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+        torch.distributed.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(x, world):
     if world == 1:
         return x
-    import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return float(t.item())
 
 
-def scan_inputs(N, A, seed):
-    """BASELINE.md §3 inputs: r~N(0,1), V~N(0,1), done~Bernoulli(0.01), generated in HBM."""
-    dev = torch.device("cuda")
-    g = torch.Generator(device=dev).manual_seed(seed)
-    r = torch.randn(N, A, generator=g, device=dev)
-    v = torch.randn(N + 1, A, generator=g, device=dev)
-    d = torch.rand(N, A, generator=g, device=dev) < 0.01
-    return r, v, d
+# ----------------------------------------------------------------------------- live kernel probe
+class CallProbe:
+    """Wraps DualHeadNet._call so that every launch of one C-ABI entry point with one geometry is
+    bracketed by HIP events on the launch stream (torch's current stream)."""
+
+    def __init__(self, net, fn_name, match):
+        self.net, self.fn_name, self.match = net, fn_name, match
+        self.events = []
+        self.enabled = False
+        self._orig = net._call
+        net._call = self._call
+
+    def _call(self, fn_name, *a):
+        if self.enabled and fn_name == self.fn_name and self.match(a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._orig(fn_name, *a)
+            e1.record()
+            self.events.append((e0, e1))
+        else:
+            self._orig(fn_name, *a)
+
+    def avg_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
 
 
-def run_scan(lib, r, v, d, adv, ret, N, A, gamma, lam_a, lam_r, stream):
+# ----------------------------------------------------------------------------- GAE scan section
+def bench_scan(lib, N, A_big, A_cfg):
     from ppo_amd import _lib
-    rc = lib.ppo_gae_scan_f32(r.data_ptr(), v.data_ptr(), v[N].data_ptr(), d.data_ptr(), _lib.PPO_TERM_U8,
-                              adv.data_ptr(), ret.data_ptr(), N, A, A, gamma, lam_a, lam_r, _lib.PPO_SCAN_AUTO,
-                              stream)
-    _lib.check(rc, "ppo_gae_scan_f32")
+    out = {}
+    for tag, A, reps in (("bandwidth", A_big, 10), ("config", A_cfg, 50)):
+        dev = torch.device("cuda")
+        g = torch.Generator(device=dev).manual_seed(0)
+        r = torch.randn(N, A, generator=g, device=dev)
+        v = torch.randn(N + 1, A, generator=g, device=dev)
+        d = torch.rand(N, A, generator=g, device=dev) < 0.01
+        adv, ret = torch.empty_like(r), torch.empty_like(r)
+
+        def go():
+            rc = lib.ppo_gae_scan_f32(r.data_ptr(), v.data_ptr(), v[N].data_ptr(), d.data_ptr(), _lib.PPO_TERM_U8,
+                                      adv.data_ptr(), ret.data_ptr(), N, A, A, 0.999, 0.95, 0.95, _lib.PPO_SCAN_AUTO,
+                                      torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "ppo_gae_scan_f32")
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for k in range(reps):
+            go()
+            ev[k + 1].record()
+        torch.cuda.synchronize()
+        ms = sum(ev[k].elapsed_time(ev[k + 1]) for k in range(reps)) / reps
+        gbps = SCAN_BYTES_PER_ELEM * N * A / (ms * 1e-3) / 1e9
+        out[tag] = {"N": N, "A": A, "avg_kernel_us": round(ms * 1e3, 2), "achieved_GBps": round(gbps, 1),
+                    "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+                    "kernel": "gae_columns_kernel" if A > 65536 else "gae_tiles_kernel"}
+        if tag == "bandwidth":
+            from oracle import returns as O
+            cols = torch.arange(0, A, max(1, A // 129), device=dev)[:129]
+            oa, orr = O.gae_and_returns(r[:, cols].cpu().numpy(), v[:N][:, cols].cpu().numpy(), v[N][cols].cpu().numpy(),
+                                        d[:, cols].cpu().numpy(), 0.999, 0.95, 0.95)
+            out[tag]["bit_exact_vs_oracle"] = bool(np.array_equal(adv[:, cols].cpu().numpy(), oa) and
+                                                   np.array_equal(ret[:, cols].cpu().numpy(), orr))
+    out["peak_GBps"] = HBM_PEAK_GBPS
+    out["algorithmic_bytes_per_element"] = SCAN_BYTES_PER_ELEM
+    return out
 
 
-def cpu_baseline(N):
-    """The oracle (scalar C port of rl/returns.py, 1 thread) on a bounded sample of the
-    same workload: N x 65536 columns, repeated for ~10 s."""
-    from oracle import returns as O
-    A = 65536
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(N, A, epochs, mb):
+    """The PPO iteration on the host through plain torch CPU ops (oracle/model_torch.py), bounded:
+    time one rollout forward of `fb` observations and one train minibatch of `tb` samples, then
+    extrapolate to a full iteration of N*A env steps."""
+    from oracle import model_torch as R, returns as O
+    from ppo_amd.models import ImpalaSpec, init_impala_parameters
+    threads = torch.get_num_threads()
+    torch.manual_seed(1)
+    init = init_impala_parameters(ImpalaSpec((4, 84, 84)), 6, 1, 0.1, True)
+    fb, tb = 64, 64
     rng = np.random.default_rng(0)
+    xf = torch.from_numpy(rng.integers(0, 256, (fb, 4, 84, 84), dtype=np.uint8))
+    xt = torch.from_numpy(rng.integers(0, 256, (tb, 4, 84, 84), dtype=np.uint8))
+    actions = torch.from_numpy(rng.integers(0, 6, (tb,)))
+    lpac = torch.full((tb,), -1.79)
+    adv = torch.from_numpy(rng.normal(size=(tb,)).astype(np.float32))
+    ret = torch.from_numpy(rng.normal(size=(tb, 1)).astype(np.float32))
+    sd = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.Adam([p for p in sd.values()], lr=2.5e-4, eps=1e-5)
+
+    def fwd():
+        with torch.no_grad():
+            R.forward(init, xf.float() / 255.0)
+
+    def train():
+        opt.zero_grad(set_to_none=True)
+        R.ppo_loss(R.forward(sd, xt.float() / 255.0), actions, lpac, adv, ret).backward()
+        torch.nn.utils.clip_grad_norm_([p for p in sd.values() if p.grad is not None], 20.0)
+        opt.step()
+    times = {}
+    for name, fn in (("fwd", fwd), ("train", train)):
+        fn()
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 6.0 and reps < 20:
+            fn()
+            reps += 1
+        times[name] = (time.perf_counter() - t0) / reps
     r = rng.normal(size=(N, A)).astype(np.float32)
     v = rng.normal(size=(N + 1, A)).astype(np.float32)
     d = rng.random((N, A)) < 0.01
-    O.gae_and_returns(r, v[:N], v[N], d, 0.999, 0.95, 0.95)  # warm-up (+ builds the oracle)
-    best, total, reps = 1e30, 0.0, 0
-    while total < 10.0 and reps < 50:
-        t0 = time.perf_counter()
-        O.gae_and_returns(r, v[:N], v[N], d, 0.999, 0.95, 0.95)
-        dt = time.perf_counter() - t0
-        best = min(best, dt)
-        total += dt
-        reps += 1
-    return {"value": round(BYTES_PER_ELEM * N * A / best / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/returns_oracle.c gae+td_lambda, N={N} A={A} bool terminals, best of {reps}",
-            "melem_per_s": round(N * A / best / 1e6, 1), "host_cores_available": os.cpu_count()}
-
-
-def main():
-    args = parse()
-    world, rank, local = init_dist(args)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    from ppo_amd import _lib
-    lib = _lib.load()
-    N, A = args.n_steps, args.scan_envs
-    gamma, lam = 0.999, 0.95  # rl/config.py:769-773
-    r, v, d = scan_inputs(N, A, seed=rank)
-    adv = torch.empty_like(r)
-    ret = torch.empty_like(r)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    for _ in range(args.warmup):
-        run_scan(lib, r, v, d, adv, ret, N, A, gamma, lam, lam, stream)
-    barrier(world)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    ev[0].record()
-    for k in range(args.steps):
-        run_scan(lib, r, v, d, adv, ret, N, A, gamma, lam, lam, stream)
-        ev[k + 1].record()
+    O.gae_and_returns(r, v[:N], v[N], d, 0.999, 0.95, 0.95)
+    t_scan = time.perf_counter() - t0
+    per_iter = (N + 1) * A * times["fwd"] / fb + epochs * N * A * times["train"] / tb + t_scan
+    return {"value": round(N * A / per_iter, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU restatement (oracle/model_torch.py): 1 rollout forward of {fb} obs "
+                      f"({times['fwd']*1e3:.0f} ms) + 1 PPO minibatch of {tb} ({times['train']*1e3:.0f} ms) + C-oracle GAE "
+                      f"scan {N}x{A} ({t_scan*1e3:.1f} ms), extrapolated to one iteration of {N*A} env steps",
+            "host_cores_available": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    a = parse()
+    world, rank, local = init_dist()
+    from ppo_amd import _lib, envs, logger, models, rollout
+    from ppo_amd.config import args
+    lib = _lib.load()
+    N, A = a.n_steps, a.agents
+    mb = 256
+    args.setup([f"--agents={A}", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala",
+                "--env_type=synthetic", "--env_embed_time=False", "--seed=1", f"--device=cuda:{local}",
+                f"--policy_opt_mini_batch_size={mb * world}", "--policy_opt_epochs=2", "--disable_logging=True",
+                "--upload_batch=True", "--env_reward_normalization=off"])
+    torch.manual_seed(1)
+    np.random.seed(1 + rank)
+    obs_shape, n_actions = envs.get_env_spec()
+    model = models.TVFModel(encoder="impala", input_dims=obs_shape, actions=n_actions, device=f"cuda:{local}",
+                            architecture="single", hidden_units=args.model.hidden_units, head_scale=args.model.head_scale,
+                            head_bias=args.model.head_bias)
+    runner = rollout.Runner(model, logger.Logger(quiet=True))
+    runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
+    runner.reset()
+    # dominant kernel of the step (profiles/: largest total time): weight gradient of the 16->16 42x42 convs
+    probe = CallProbe(model.policy_net, "ppo_conv3x3_backward_weight_f32",
+                      lambda c: (c[8], c[9], c[10], c[11]) == (16, 16, 42, 42))
+    probe_flops = 2 * 9 * 16 * 16 * 42 * 42 * mb
+
+    def iteration():
+        runner.generate_rollout()
+        runner.calculate_returns()
+        runner.train()
+
+    for _ in range(a.warmup):
+        iteration()
     barrier(world)
-    wall = time.perf_counter() - t0
-    wall = max_over_ranks(wall, world)
-    kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
-    kern_avg_s = sum(kern_ms) / len(kern_ms) / 1e3
+    probe.enabled = True
+    phase = {"rollout": 0.0, "returns": 0.0, "train": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        t = time.perf_counter()
+        runner.generate_rollout()
+        phase["rollout"] += time.perf_counter() - t
+        t = time.perf_counter()
+        runner.calculate_returns()
+        phase["returns"] += time.perf_counter() - t
+        t = time.perf_counter()
+        runner.train()
+        phase["train"] += time.perf_counter() - t
+    barrier(world)
+    wall = max_over_ranks(time.perf_counter() - t0, world)
+    probe.enabled = False
+    stats = runner.fetch_stats()
 
-    # parity gate printed with the number: sampled columns vs the oracle (columns are independent)
-    parity = None
-    if rank == 0:
-        from oracle import returns as O
-        cols = torch.arange(0, A, max(1, A // 257), device="cuda")[:257]
-        oa, orr = O.gae_and_returns(r[:, cols].cpu().numpy(), v[:N][:, cols].cpu().numpy(),
-                                    v[N][cols].cpu().numpy(), d[:, cols].cpu().numpy(), gamma, lam, lam)
-        parity = bool(np.array_equal(adv[:, cols].cpu().numpy(), oa) and np.array_equal(ret[:, cols].cpu().numpy(), orr))
-
-    bytes_per_launch = BYTES_PER_ELEM * N * A
-    achieved = bytes_per_launch / kern_avg_s / 1e9
+    env_steps = world * N * A * a.steps
+    kern_ms = probe.avg_ms()
+    tflops = probe_flops / (kern_ms * 1e-3) / 1e12
+    samples_fwd = (N + 1) * A + args.policy_opt.epochs * N * A
+    samples_bwd = args.policy_opt.epochs * N * A
+    model_tflops = (samples_fwd + 2 * samples_bwd) * FWD_MFLOP_PER_SAMPLE * 1e6 * a.steps / wall / 1e12
     out = {
-        "metric": "GAE-scan HBM GB/s",
-        "value": round(world * bytes_per_launch * args.steps / wall / 1e9, 2),
-        "unit": "GB/s",
+        "metric": "env-steps/sec (Pong-shaped synthetic, 256 envs/GPU)",
+        "value": round(env_steps / wall, 1),
+        "unit": "env-steps/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 2),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64 carry / f32 io",
+        "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"fused GAE+lambda-returns scan, N={N}, A={A} per GPU, bool terminals, "
-                               f"gamma={gamma} lambda={lam}", "regime": "columns" if A > 65536 else "tiles"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "gae_columns_kernel" if A > 65536 else "gae_tiles_kernel",
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "avg_kernel_ms": round(kern_avg_s * 1e3, 4)},
-        "parity_bit_exact_vs_oracle": parity,
+        "config": {"workload": f"PPO iteration: {A} envs/GPU x {N} steps, obs {obs_shape} uint8, IMPALA-CNN single "
+                               f"architecture ({model.model_size()} params), {args.policy_opt.epochs} policy epochs, "
+                               f"global minibatch {mb * world}, Adam, synthetic env (uniform uint8 obs, N(0,1) reward, "
+                               f"p_done 0.01)", "envs_per_gpu": A, "n_steps": N, "global_minibatch": mb * world,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "conv3x3_wgrad_kernel<16,16,42,42> (+ its slab reduce, one C-ABI call)",
+                     "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
+                     "launches_timed": len(probe.events)},
+        "phase_seconds_per_step": {k: round(v / a.steps, 4) for k, v in phase.items()},
+        "model_tflops_whole_step": round(model_tflops / world, 2),
+        "train_stats": {k: round(float(v), 6) for k, v in stats.items()},
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N)
+        if world == 1 and not a.no_scan:
+            out["gae_scan"] = bench_scan(lib, N, a.scan_envs, A)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, A, args.policy_opt.epochs, mb)
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

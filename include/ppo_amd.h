@@ -161,11 +161,13 @@ int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *out, int ac
  *                u from `uniform` [B,n_actions] if given, else from a counter-based generator
  *                keyed by (seed, offset + b*n_actions + a);
  *   greedy != 0: argmax of the logits (rl/models.py:479, run_evaluation.py:621-623).
- * Outputs (each nullable): log_policy [B,n_actions], actions [B] int32, log_pac [B] = log_policy[b, action].
+ * Outputs (each nullable): log_policy [B,n_actions], actions [B] int32, log_pac [B] = log_policy[b, action],
+ * raw_policy [B,n_actions] (the logits) and values [B,n_value_heads] (the value-head columns), i.e. the
+ * per-step rows the rollout buffer stores (rl/rollout.py:807-815), written straight into it.
  */
 int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_actions, float temperature, const float *uniform,
                        uint64_t seed, uint64_t offset, int greedy, float *log_policy, int32_t *actions,
-                       float *log_pac, void *stream);
+                       float *log_pac, float *raw_policy, float *values, int n_value_heads, void *stream);
 
 /*
  * PPO minibatch loss, forward + gradient w.r.t. the head outputs
@@ -179,7 +181,9 @@ int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_actions, float 
 int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_value_heads, const int32_t *actions,
                      const float *old_log_pac, const float *old_log_policy, const float *advantages,
                      const float *returns, float eps_clip, float ent_coef, float vf_coef, float grad_scale,
-                     float *dheads, float *stats, void *stream);
+                     float *dheads, float *stats, const int32_t *index, void *stream);
+/* index (nullable, [B] int32): sample b reads actions / old_log_pac / old_log_policy / advantages /
+ * returns at row index[b] of the whole-batch arrays (the minibatch permutation), so those need no gather. */
 
 /*
  * One optimiser step on a flat parameter buffer: global-norm clip (clip_grad_norm_,
@@ -192,6 +196,44 @@ size_t ppo_adam_workspace_bytes(void);
 int ppo_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
                       double lr, double beta1, double beta2, double eps, float max_grad_norm, float grad_div,
                       void *workspace, float *grad_norm_out, void *stream);
+
+/*
+ * dst[r, :] = src[index[r], :] for r < n_rows; rows are row_bytes bytes (minibatch gather of
+ * observations and per-sample data by a permutation; replaces the host fancy-indexing + upload of
+ * rl/rollout.py:2349-2372).  Indices outside [0, n_src_rows) read row 0.
+ */
+int ppo_gather_rows(const void *src, int64_t row_bytes, int64_t n_src_rows, const int32_t *index, int n_rows,
+                    void *dst, void *stream);
+
+/*
+ * Batch-level advantage normalisation (Runner.train_policy, rl/rollout.py:1887-1900):
+ *   ppo_moments_f64   moments[0..2] = { sum x, sum x^2, n } in float64 (device), fixed-order reduction;
+ *                     a data-parallel run all-reduces the three doubles before normalising
+ *   ppo_normalize_f32 out = (x - mean) / (std + eps), population std; mean_std_out (nullable, [2])
+ * workspace: ppo_moments_workspace_bytes() bytes.
+ */
+size_t ppo_moments_workspace_bytes(void);
+int ppo_moments_f64(const float *x, int64_t n, double *moments, void *workspace, void *stream);
+int ppo_normalize_f32(const float *x, int64_t n, const double *moments, float eps, float *out, float *mean_std_out,
+                      void *stream);
+
+/* ------------------------------------------------------------------------
+ * Synthetic vectorised environment (HOST pointers; runs on host threads).
+ * The benchmark workload of SURVEY.md §8(d): obs uint8 i.i.d. uniform, reward ~ N(0,1),
+ * done ~ Bernoulli(p_done), auto-reset; stands where the reference has the
+ * HybridAsyncVectorEnv worker processes (rl/hybridVecEnv.py:49-203).  obs_out is a
+ * caller-owned host buffer [n_envs, obs_bytes] (pinned, so the trainer can H2D it
+ * asynchronously); every value depends only on (seed, env_offset + env, env step count).
+ * actions[e] < 0 skips env e (rl/wrappers.py:1393-1418).  Per-env outputs other than
+ * obs_out are nullable: reward [n] f32, done [n] u8, time [n] i32 (steps since reset, before
+ * the auto-reset), ep_score [n] f32, ep_len [n] i32.
+ * ---------------------------------------------------------------------- */
+void *ppo_synth_env_create(int n_envs, int64_t obs_bytes, uint64_t seed, double p_done, int64_t env_offset,
+                           int n_threads);
+void ppo_synth_env_destroy(void *env);
+int ppo_synth_env_reset(void *env, uint8_t *obs_out);
+int ppo_synth_env_step(void *env, const int32_t *actions, uint8_t *obs_out, float *reward_out, uint8_t *done_out,
+                       int32_t *time_out, float *ep_score_out, int32_t *ep_len_out);
 
 #ifdef __cplusplus
 }

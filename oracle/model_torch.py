@@ -1,9 +1,17 @@
-"""Plain-PyTorch restatement of the single-architecture IMPALA policy/value network and PPO loss
-(test infrastructure: the "plain PyTorch reference of the same op" for the floating-point kernels).
+"""oracle/model_torch.py — TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Plain-PyTorch (CPU or any device, any float dtype) restatement of the reference's
+single-architecture IMPALA policy/value network and PPO loss: the "plain PyTorch reference of the
+same op" for the floating-point kernels, and — because the reference's own CPU path IS these torch
+operators (`--device=cpu`, rl/config.py:731) — the `cpu_baseline` leg of bench.py.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline may import it; ppo_amd never does.
 
 Follows rl/models.py:90-99,433-508 and rl/impala.py:69-82,102-109 of the reference; takes a
-``state_dict`` with the reference's key names (relative to policy_net) in any float dtype, so it
-doubles as a float64 yardstick for deciding which fp32 implementation is closer to exact.
+``state_dict`` with the reference's key names (relative to policy_net).
+
+Parity: PINNED.  tests/golden/model_golden.npz (outputs of the imported reference) is reproduced by
+`forward` / `ppo_loss` to fp32 round-off (loss 0.98257291 on minibatch 0, identical digits; all
+gradients within 2e-6 of the reference's), checked in tests/test_oracle_model.py.
 """
 import torch
 import torch.nn.functional as F

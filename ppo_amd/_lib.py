@@ -43,8 +43,16 @@ SIGNATURES = {
     "ppo_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "ppo_gemm_f32": (_i, [_vp, _i64, _i64, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "ppo_colsum_f32": (_i, [_vp, _i, _i, _i64, _vp, _i, _vp]),
-    "ppo_policy_act_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp]),
-    "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "ppo_policy_act_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ppo_gather_rows": (_i, [_vp, _i64, _i64, _vp, _i, _vp, _vp]),
+    "ppo_moments_workspace_bytes": (_sz, []),
+    "ppo_moments_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "ppo_normalize_f32": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),
+    "ppo_synth_env_create": (_vp, [_i, _i64, _u64, _d, _i64, _i]),
+    "ppo_synth_env_destroy": (None, [_vp]),
+    "ppo_synth_env_reset": (_i, [_vp, _vp]),
+    "ppo_synth_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
 }

@@ -1,0 +1,222 @@
+"""Run configuration — host mirror of the reference's rl/config.py for the flags the PPO hot path reads.
+
+Same flag names, defaults and access pattern as the reference (`rl.config.args`, a global
+singleton read at call time; grouped flags appear as `--<prefix>_<name>` and are read as
+`args.<prefix>.<name>`, rl/config.py:38-185).  Defaults cite rl/config.py line numbers.
+Flags of out-of-scope subsystems (distillation, RND, replay, hashing, ...) are
+accepted and ignored with a note, so existing launch lines keep working.
+"""
+import argparse
+import sys
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+class _Group:
+    """A prefixed flag group: fields declared as (name, type, default, help)."""
+    FIELDS = ()
+
+    def __init__(self, prefix):
+        self._prefix = prefix
+        for name, _t, default, _h in self.FIELDS:
+            setattr(self, name, default)
+
+    def add(self, parser):
+        for name, t, default, h in self.FIELDS:
+            kw = dict(type=str2bool, nargs="?", const=True) if t is bool else dict(type=t)
+            parser.add_argument(f"--{self._prefix}_{name}", default=default, help=h, **kw)
+
+    def update(self, ns):
+        for name, *_ in self.FIELDS:
+            setattr(self, name, getattr(ns, f"{self._prefix}_{name}"))
+
+    def flatten(self):
+        return {f"{self._prefix}_{name}": getattr(self, name) for name, *_ in self.FIELDS}
+
+
+class OptimizerConfig(_Group):  # rl/config.py:249-311
+    FIELDS = (
+        ("optimizer", str, "adam", "[adam]"),
+        ("epochs", int, 2, "training epochs per batch"),
+        ("mini_batch_size", int, 256, "examples per optimisation step (global, across ranks)"),
+        ("lr", float, 2.5e-4, "learning rate"),
+        ("lr_anneal", bool, False, "anneal learning rate linearly to 0"),
+        ("adam_epsilon", float, 1e-5, "Adam epsilon"),
+        ("adam_beta1", float, 0.9, "Adam beta1"),
+        ("adam_beta2", float, 0.999, "Adam beta2"),
+    )
+
+
+class ModelConfig(_Group):  # rl/config.py:458-476
+    FIELDS = (
+        ("architecture", str, "dual", "[dual|single]  (north-star PPO = single)"),
+        ("encoder", str, "nature", "[impala|mlp]  (nature has no HIP path)"),
+        ("encoder_args", str, None, "dict of encoder arguments"),
+        ("hidden_units", int, 256, "encoder output features"),
+        ("head_scale", float, 0.1, "orthogonal-init gain of the heads"),
+        ("head_bias", bool, True, "bias on the output heads"),
+    )
+
+
+class EnvConfig(_Group):  # rl/config.py:495-603
+    FIELDS = (
+        ("name", str, "Pong", "environment name"),
+        ("type", str, "atari", "[atari|procgen|mujoco|classic|synthetic]"),
+        ("embed_time", bool, True, "append a time channel"),
+        ("embed_action", bool, True, "embed last action"),
+        ("reward_normalization", str, "rms", "[off|rms]"),
+        ("reward_clip", float, 10.0, "clip normalised rewards"),
+        ("warmup_period", int, 250, "random warm-up steps to desynchronise envs"),
+        ("timeout", int, 0, "episode step limit (0 = env default)"),
+        ("synthetic_done_prob", float, 0.01, "synthetic env: per-step termination probability"),
+        ("synthetic_threads", int, 8, "synthetic env: host threads generating observations"),
+    )
+
+
+class TVFConfig(_Group):  # rl/config.py:209-246
+    FIELDS = (
+        ("enabled", bool, False, "truncated value functions"),
+        ("value_heads", int, 128, "number of horizon heads"),
+        ("max_horizon", int, 30000, "longest horizon"),
+        ("gamma", float, None, "TVF discount (None = gamma)"),
+        ("coef", float, 1.0, "TVF loss coefficient"),
+        ("head_spacing", str, "geometric", "[geometric|linear]"),
+        ("return_mode", str, "advanced", "[standard|advanced|full|...]"),
+        ("return_distribution", str, "exponential", "[fixed|exponential|uniform|hyperbolic|quadratic]"),
+        ("return_samples", int, 8, "n-step samples per horizon"),
+        ("return_use_log_interpolation", bool, False, "interpolate in log-horizon space"),
+    )
+
+
+class Config:
+    def __init__(self):
+        self.policy_opt = OptimizerConfig("policy_opt")
+        self.value_opt = OptimizerConfig("value_opt")
+        self.model = ModelConfig("model")
+        self.env = EnvConfig("env")
+        self.tvf = TVFConfig("tvf")
+        self._groups = (self.policy_opt, self.value_opt, self.model, self.env, self.tvf)
+        # top-level defaults (rl/config.py line numbers)
+        self.agents = 256              # :791
+        self.n_steps = 256             # :790
+        self.gamma = 0.999             # :769
+        self.lambda_policy = 0.95      # :772
+        self.lambda_value = 0.95       # :773
+        self.ppo_epsilon = 0.2         # :789
+        self.entropy_bonus = 0.01      # :785
+        self.ppo_vf_coef = 0.5         # :784
+        self.max_grad_norm = 20.0      # :775
+        self.grad_clip_mode = "global_norm"  # :776
+        self.advantage_epsilon = 1e-8  # :792
+        self.advantage_clipping = None
+        self.max_micro_batch_size = 512  # :760
+        self.device = "cpu"            # :731 (the reference default; this build requires a GPU)
+        self.upload_batch = False      # :732
+        self.observation_normalization = False  # :756
+        self.observation_scaling = "scaled"     # :755
+        self.seed = -1                 # :749
+        self.epochs = 50.0             # millions of env steps
+        self.limit_epochs = None
+        self.benchmark_mode = False
+        self.disable_logging = False   # :733
+        self.disable_ev = False
+        self.output_folder = "./"
+        self.experiment_name = "Run"
+        self.run_name = "run"
+        self.restore = "never"
+        self.checkpoint_every = int(10e6)
+        self.workers = -1              # :722
+        self.threads = 2               # :723
+        self.precision = "medium"      # :764
+        self.use_intrinsic_rewards = False
+        self.log_folder = None
+        self._ignored = []
+
+    # ---- properties the reference derives (rl/config.py:885-901)
+    @property
+    def batch_size(self):
+        return self.n_steps * self.agents
+
+    @property
+    def tvf_return_n_step(self):
+        return round(1 / (1 - self.lambda_value)) if self.lambda_value < 1 else self.n_steps
+
+    def build_parser(self):
+        p = argparse.ArgumentParser(description="MI355X-native PPO trainer (drop-in for dremovd/PPO train.py)")
+        a = p.add_argument
+        a("--agents", type=int, default=self.agents)
+        a("--n_steps", type=int, default=self.n_steps)
+        a("--gamma", type=float, default=self.gamma)
+        a("--lambda_policy", type=float, default=self.lambda_policy)
+        a("--lambda_value", type=float, default=self.lambda_value)
+        a("--ppo_epsilon", type=float, default=self.ppo_epsilon)
+        a("--entropy_bonus", type=float, default=self.entropy_bonus)
+        a("--ppo_vf_coef", type=float, default=self.ppo_vf_coef)
+        a("--max_grad_norm", type=float, default=self.max_grad_norm)
+        a("--grad_clip_mode", type=str, default=self.grad_clip_mode, help="[off|global_norm]")
+        a("--advantage_epsilon", type=float, default=self.advantage_epsilon)
+        a("--advantage_clipping", type=float, default=None)
+        a("--max_micro_batch_size", type=int, default=self.max_micro_batch_size)
+        a("--device", type=str, default=self.device)
+        a("--upload_batch", type=str2bool, nargs="?", const=True, default=self.upload_batch)
+        a("--observation_normalization", type=str2bool, nargs="?", const=True, default=False)
+        a("--observation_scaling", type=str, default="scaled")
+        a("--seed", type=int, default=self.seed)
+        a("--epochs", type=float, default=self.epochs, help="millions of env steps to train for")
+        a("--limit_epochs", type=float, default=None)
+        a("--benchmark_mode", type=str2bool, nargs="?", const=True, default=False)
+        a("--disable_logging", type=str2bool, nargs="?", const=True, default=False)
+        a("--disable_ev", type=str2bool, nargs="?", const=True, default=False)
+        a("--output_folder", type=str, default=self.output_folder)
+        a("--experiment_name", type=str, default=self.experiment_name)
+        a("--run_name", type=str, default=self.run_name)
+        a("--restore", type=str, default=self.restore, help="[never|auto|always]")
+        a("--checkpoint_every", type=int, default=self.checkpoint_every)
+        a("--workers", type=int, default=self.workers)
+        a("--threads", type=int, default=self.threads)
+        a("--precision", type=str, default=self.precision, help="[low|medium|high]; all run exact fp32 here")
+        a("--use_intrinsic_rewards", type=str2bool, nargs="?", const=True, default=False)
+        for g in self._groups:
+            g.add(p)
+        return p
+
+    def setup(self, argv=None):
+        """Parse argv (default sys.argv[1:]) like rl.config.args.setup() (rl/config.py:709-801)."""
+        parser = self.build_parser()
+        ns, unknown = parser.parse_known_args(sys.argv[1:] if argv is None else argv)
+        for k, v in vars(ns).items():
+            if any(k.startswith(g._prefix + "_") for g in self._groups):
+                continue
+            setattr(self, k, v)
+        for g in self._groups:
+            g.update(ns)
+        self._ignored = [u for u in unknown if u.startswith("--")]
+        self.verify()
+        return self
+
+    def verify(self):
+        if self.model.architecture not in ("single", "dual"):
+            raise ValueError(f"Invalid architecture {self.model.architecture}, use [dual|single]")
+        if self.grad_clip_mode not in ("off", "global_norm"):
+            raise ValueError("Invalid clip_mode.")
+        if self.tvf.gamma is None:
+            self.tvf.gamma = self.gamma
+        if self.log_folder is None:
+            self.log_folder = self.output_folder
+
+    def flatten(self):
+        d = {k: v for k, v in vars(self).items() if not k.startswith("_") and not isinstance(v, _Group)}
+        for g in self._groups:
+            d.update(g.flatten())
+        return d
+
+
+args = Config()

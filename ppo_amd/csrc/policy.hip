@@ -36,11 +36,16 @@ __global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict_
                                                         float temperature, const float *__restrict__ uniform,
                                                         uint64_t seed, uint64_t offset, int greedy,
                                                         float *__restrict__ log_policy, int32_t *__restrict__ actions,
-                                                        float *__restrict__ log_pac)
+                                                        float *__restrict__ log_pac, float *__restrict__ raw_policy,
+                                                        float *__restrict__ values, int vh)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float *z = heads + (size_t)b * ldo;
+    if (raw_policy)
+        for (int a = 0; a < nA; ++a) raw_policy[(size_t)b * nA + a] = z[a];
+    if (values)
+        for (int i = 0; i < vh; ++i) values[(size_t)b * vh + i] = z[nA + i];
     float logits[kMaxActions];
     float mx = -INFINITY;
 #pragma unroll 4
@@ -80,11 +85,12 @@ __global__ __launch_bounds__(64) void ppo_loss_kernel(
     const float *__restrict__ heads, int B, int ldo, int nA, int vh, const int32_t *__restrict__ actions,
     const float *__restrict__ old_log_pac, const float *__restrict__ old_log_policy,
     const float *__restrict__ advantages, const float *__restrict__ returns, float eps_clip, float ent_coef,
-    float vf_coef, float grad_scale, float *__restrict__ dheads, float *__restrict__ stats)
+    float vf_coef, float grad_scale, float *__restrict__ dheads, float *__restrict__ stats, const int32_t *__restrict__ index)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float *z = heads + (size_t)b * ldo;
+    const int sb = index ? index[b] : b;  // row of this sample in the (un-gathered) batch arrays
     float lp[kMaxActions];
     float mx = -INFINITY;
     for (int a = 0; a < nA; ++a) {
@@ -99,12 +105,12 @@ __global__ __launch_bounds__(64) void ppo_loss_kernel(
         lp[a] -= lse;
         const float p = expf(lp[a]);
         entropy -= p * lp[a];
-        if (old_log_policy) kl_true += p * (lp[a] - old_log_policy[(size_t)b * nA + a]);
+        if (old_log_policy) kl_true += p * (lp[a] - old_log_policy[(size_t)sb * nA + a]);
     }
-    const int act = actions[b];
-    const float adv = advantages[b];
+    const int act = actions[sb];
+    const float adv = advantages[sb];
     const float logpac = lp[act];
-    const float ratio = expf(logpac - old_log_pac[b]);
+    const float ratio = expf(logpac - old_log_pac[sb]);
     const float clipped_ratio = fminf(fmaxf(ratio, 1.f - eps_clip), 1.f + eps_clip);
     const float s1 = ratio * adv, s2 = clipped_ratio * adv;
     const float loss_clip = fminf(s1, s2);
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(64) void ppo_loss_kernel(
     float vloss = 0.f;
     float *dz = dheads + (size_t)b * ldo;
     for (int i = 0; i < vh; ++i) {
-        const float diff = z[nA + i] - returns[(size_t)b * vh + i];
+        const float diff = z[nA + i] - returns[(size_t)sb * vh + i];
         vloss += vf_coef * diff * diff;
         dz[nA + i] = grad_scale * 2.f * vf_coef * diff;  // d(-gain)/dV
     }
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(64) void ppo_loss_kernel(
         s[ST_ENTROPY] = entropy;
         s[ST_VALUE_LOSS] = vloss;
         s[ST_CLIPPED] = fabsf(ratio - 1.f) > eps_clip ? 1.f : 0.f;
-        s[ST_KL_APPROX] = old_log_pac[b] - logpac;
+        s[ST_KL_APPROX] = old_log_pac[sb] - logpac;
         s[ST_KL_TRUE] = kl_true;
         s[ST_GAIN] = loss_clip + ent_coef * entropy - vloss;
         s[ST_RATIO] = ratio;
@@ -151,24 +157,26 @@ __global__ __launch_bounds__(64) void ppo_loss_kernel(
 
 extern "C" int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_actions, float temperature,
                                   const float *uniform, uint64_t seed, uint64_t offset, int greedy, float *log_policy,
-                                  int32_t *actions, float *log_pac, void *stream)
+                                  int32_t *actions, float *log_pac, float *raw_policy, float *values,
+                                  int n_value_heads, void *stream)
 {
     using namespace ppo;
-    if (B < 0 || n_actions <= 0 || n_actions > kMaxActions || ldo < n_actions)
+    if (B < 0 || n_actions <= 0 || n_actions > kMaxActions || n_value_heads < 0 || ldo < n_actions + n_value_heads)
         return fail(PPO_E_INVALID, "ppo_policy_act_f32: bad shape (B=%d n_actions=%d ldo=%d, max %d actions)", B,
                     n_actions, ldo, kMaxActions);
     if (B == 0) return PPO_OK;
     if (!heads) return fail(PPO_E_INVALID, "ppo_policy_act_f32: null heads");
     if (!(temperature > 0.f)) return fail(PPO_E_INVALID, "ppo_policy_act_f32: temperature must be > 0 (use greedy=1 for argmax)");
     hipLaunchKernelGGL(policy_act_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,
-                       n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac);
+                       n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac, raw_policy,
+                       values, n_value_heads);
     return check_launch("policy_act_kernel");
 }
 
 extern "C" int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_value_heads,
                                 const int32_t *actions, const float *old_log_pac, const float *old_log_policy,
                                 const float *advantages, const float *returns, float eps_clip, float ent_coef,
-                                float vf_coef, float grad_scale, float *dheads, float *stats, void *stream)
+                                float vf_coef, float grad_scale, float *dheads, float *stats, const int32_t *index, void *stream)
 {
     using namespace ppo;
     if (B < 0 || n_actions <= 0 || n_actions > kMaxActions || n_value_heads < 0 || ldo < n_actions + n_value_heads)
@@ -178,6 +186,6 @@ extern "C" int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_action
         return fail(PPO_E_INVALID, "ppo_ppo_loss_f32: null pointer");
     hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo, n_actions,
                        n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns, eps_clip, ent_coef,
-                       vf_coef, grad_scale, dheads, stats);
+                       vf_coef, grad_scale, dheads, stats, index);
     return check_launch("ppo_loss_kernel");
 }

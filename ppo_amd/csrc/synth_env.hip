@@ -1,0 +1,216 @@
+// Synthetic vectorised environment stepped on host cores (no device code in this file).
+//
+// The benchmark workload of SURVEY.md §8(d) / BASELINE.md §3: observations are uint8 i.i.d.
+// uniform[0,255] from a seeded counter-based generator, reward ~ N(0,1), done ~ Bernoulli(p),
+// info = {time, ep_length, ep_score}; episodes auto-reset like gym's vector envs
+// (rl/hybridVecEnv.py:24-46).  It stands where the reference has ALE / Procgen / MuJoCo worker
+// processes (rl/hybridVecEnv.py:49-203): same call shape — step(actions[A]) fills obs, reward,
+// done for all A envs — with the observation written straight into a caller-owned (pinned) host
+// buffer so the trainer can issue one async H2D copy per step.  Action -1 skips an env
+// (NullActionWrapper, rl/wrappers.py:1393-1418).
+//
+// A persistent pool of worker threads splits the envs; every value depends only on
+// (seed, global env index, that env's step count), so results are independent of the thread count
+// and of how envs are sharded over ranks.
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct SynthEnv {
+    int n_envs;
+    int64_t obs_bytes;
+    uint64_t seed;
+    double p_done;
+    int64_t env_offset;  // global index of env 0 (data-parallel sharding)
+    std::vector<int64_t> steps;     // per-env total step count (drives the generator)
+    std::vector<int32_t> time;      // steps since episode start
+    std::vector<float> score;       // undiscounted episode score
+    // job description for the pool
+    const int32_t *actions = nullptr;
+    uint8_t *obs = nullptr;
+    float *reward = nullptr;
+    uint8_t *done = nullptr;
+    int32_t *time_out = nullptr;
+    float *ep_score_out = nullptr;
+    int32_t *ep_len_out = nullptr;
+    bool is_reset = false;
+
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
+
+    void fill_obs(int e)
+    {
+        // 8 bytes per mix of (seed, env, step, word)
+        const uint64_t key = mix64(seed ^ mix64((uint64_t)(env_offset + e) * 0x9E3779B97F4A7C15ull + (uint64_t)steps[e]));
+        uint8_t *dst = obs + (int64_t)e * obs_bytes;
+        const int64_t n8 = obs_bytes / 8;
+        uint64_t ctr = key;
+        for (int64_t i = 0; i < n8; ++i) {
+            ctr += 0x9E3779B97F4A7C15ull;
+            const uint64_t v = mix64(ctr);
+            std::memcpy(dst + i * 8, &v, 8);
+        }
+        if (obs_bytes % 8) {
+            ctr += 0x9E3779B97F4A7C15ull;
+            const uint64_t v = mix64(ctr);
+            std::memcpy(dst + n8 * 8, &v, (size_t)(obs_bytes % 8));
+        }
+    }
+
+    void run_range(int lo, int hi)
+    {
+        for (int e = lo; e < hi; ++e) {
+            if (is_reset) {
+                steps[e] = 0;
+                time[e] = 0;
+                score[e] = 0.f;
+                fill_obs(e);
+                continue;
+            }
+            if (actions && actions[e] < 0) {  // skipped env: nothing advances, obs unchanged
+                if (reward) reward[e] = 0.f;
+                if (done) done[e] = 0;
+                if (time_out) time_out[e] = time[e];
+                if (ep_score_out) ep_score_out[e] = score[e];
+                if (ep_len_out) ep_len_out[e] = time[e];
+                continue;
+            }
+            steps[e] += 1;
+            const uint64_t k = mix64(seed * 0xD1342543DE82EF95ull + (uint64_t)(env_offset + e)) + (uint64_t)steps[e] * 3;
+            const double u1 = ((double)(mix64(k) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            const double u2 = ((double)(mix64(k + 1) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            const double u3 = ((double)(mix64(k + 2) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+            const float r = (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+            const bool d = u3 < p_done;
+            time[e] += 1;
+            score[e] += r;
+            if (reward) reward[e] = r;
+            if (done) done[e] = d ? 1 : 0;
+            if (time_out) time_out[e] = time[e];
+            if (ep_score_out) ep_score_out[e] = score[e];
+            if (ep_len_out) ep_len_out[e] = time[e];
+            if (d) {  // auto-reset: the returned obs is the first obs of the next episode
+                time[e] = 0;
+                score[e] = 0.f;
+            }
+            fill_obs(e);
+        }
+    }
+
+    void worker(int idx, int n_workers)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_start.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            const int per = (n_envs + n_workers - 1) / n_workers;
+            const int lo = idx * per;
+            const int hi = lo + per < n_envs ? lo + per : n_envs;
+            if (lo < hi) run_range(lo, hi);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+
+    void dispatch()
+    {
+        if (workers.empty()) {
+            run_range(0, n_envs);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        pending = (int)workers.size();
+        ++generation;
+        cv_start.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+}  // namespace
+
+extern "C" void *ppo_synth_env_create(int n_envs, int64_t obs_bytes, uint64_t seed, double p_done,
+                                      int64_t env_offset, int n_threads)
+{
+    if (n_envs <= 0 || obs_bytes <= 0 || n_threads < 0) {
+        ppo::fail(PPO_E_INVALID, "ppo_synth_env_create: bad arguments");
+        return nullptr;
+    }
+    auto *e = new SynthEnv();
+    e->n_envs = n_envs;
+    e->obs_bytes = obs_bytes;
+    e->seed = seed;
+    e->p_done = p_done;
+    e->env_offset = env_offset;
+    e->steps.assign(n_envs, 0);
+    e->time.assign(n_envs, 0);
+    e->score.assign(n_envs, 0.f);
+    if (n_threads > n_envs) n_threads = n_envs;
+    for (int i = 0; i < n_threads; ++i) e->workers.emplace_back(&SynthEnv::worker, e, i, n_threads);
+    return e;
+}
+
+extern "C" void ppo_synth_env_destroy(void *h)
+{
+    auto *e = static_cast<SynthEnv *>(h);
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->stop = true;
+    }
+    e->cv_start.notify_all();
+    for (auto &t : e->workers) t.join();
+    delete e;
+}
+
+extern "C" int ppo_synth_env_reset(void *h, uint8_t *obs_out)
+{
+    auto *e = static_cast<SynthEnv *>(h);
+    if (!e || !obs_out) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_reset: null");
+    e->obs = obs_out;
+    e->is_reset = true;
+    e->dispatch();
+    e->is_reset = false;
+    return PPO_OK;
+}
+
+extern "C" int ppo_synth_env_step(void *h, const int32_t *actions, uint8_t *obs_out, float *reward_out,
+                                  uint8_t *done_out, int32_t *time_out, float *ep_score_out, int32_t *ep_len_out)
+{
+    auto *e = static_cast<SynthEnv *>(h);
+    if (!e || !obs_out) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_step: null");
+    e->actions = actions;
+    e->obs = obs_out;
+    e->reward = reward_out;
+    e->done = done_out;
+    e->time_out = time_out;
+    e->ep_score_out = ep_score_out;
+    e->ep_len_out = ep_len_out;
+    e->dispatch();
+    return PPO_OK;
+}

@@ -274,13 +274,14 @@ class DualHeadNet:
         result = {"raw_policy": o[:, :nA], "value": o[:, nA:nA + self.vh], "advantage": o[:, nA + self.vh:]}
         if policy_temperature > 0:
             self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, float(policy_temperature), None, 0, 0, 1, _p(logp),
-                       None, None)
+                       None, None, None, None, self.vh)
             result["log_policy"] = logp
         else:
             # greedy / blended policy (rl/models.py:475-485): tiny [B, nA] tensors, composed from the
             # HIP log-softmax and argmax
             act = self._buf("greedy_actions", (B,), torch.int32)
-            self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, 1.0, None, 0, 0, 1, _p(logp), _p(act), None)
+            self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, 1.0, None, 0, 0, 1, _p(logp), _p(act), None,
+                       None, None, self.vh)
             argmax_policy = torch.zeros_like(logp)
             argmax_policy[torch.arange(B, device=self.device), act.long()] = 1.0
             eps = 1 + policy_temperature
@@ -353,19 +354,20 @@ class DualHeadNet:
 
     # ------------------------------------------------------------------ PPO minibatch + optimiser
     def ppo_minibatch(self, prev_state, actions, old_log_pac, old_log_policy, advantages, returns,
-                      eps_clip=0.2, ent_coef=0.01, vf_coef=0.5, loss_scale=1.0):
+                      eps_clip=0.2, ent_coef=0.01, vf_coef=0.5, loss_scale=1.0, index=None):
         """Forward, fused PPO loss, backward: gradients of mean(-gain)*loss_scale land in self.grad
         (Runner.train_policy_minibatch, rl/rollout.py:1610-1771, single architecture).
+        prev_state is the (already gathered) minibatch of observations; the per-sample arrays are
+        either minibatch-sized or, with ``index`` ([B] int32), whole-batch arrays read at index[b].
         Returns the per-sample statistics tensor [B, 8] (device)."""
         acts = self.encode(prev_state, train=True)
         o = self.heads(acts["h"], "t")
         B = o.shape[0]
         dheads = self._buf("dheads", (B, self.nh))
         stats = self._buf("loss_stats", (B, 8))
-        returns = returns.reshape(B, self.vh)
         self._call("ppo_ppo_loss_f32", _p(o), B, self.nh, self.n_actions, self.vh, _p(actions), _p(old_log_pac),
                    _p(old_log_policy), _p(advantages), _p(returns), float(eps_clip), float(ent_coef), float(vf_coef),
-                   float(loss_scale) / B, _p(dheads), _p(stats))
+                   float(loss_scale) / B, _p(dheads), _p(stats), _p(index))
         self.backward(acts, dheads)
         return stats
 
@@ -380,3 +382,111 @@ class DualHeadNet:
         self._call("ppo_adam_step_f32", _p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq),
                    self.flat.numel(), self._adam_step, float(lr), float(beta1), float(beta2), float(eps),
                    float(max_grad_norm), float(grad_div), _p(ws), _p(grad_norm_out))
+
+    # ------------------------------------------------------------------ optimiser state (checkpoints)
+    def optimizer_state_dict(self):
+        """Adam state in torch.optim.Adam's layout idea (step + per-parameter exp_avg / exp_avg_sq),
+        keyed by parameter name (rl/rollout.py:394-453 stores optimizer.state_dict())."""
+        if self.exp_avg is None:
+            return {"step": 0, "state": {}}
+        state = {}
+        for name, (o, shape) in self._offsets.items():
+            n = int(np.prod(shape))
+            state[name] = {"exp_avg": self.exp_avg[o:o + n].view(shape).clone(),
+                           "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shape).clone()}
+        return {"step": self._adam_step, "state": state}
+
+    def load_optimizer_state_dict(self, sd):
+        self._adam_step = int(sd.get("step", 0))
+        if not sd.get("state"):
+            self.exp_avg = self.exp_avg_sq = None
+            return
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        for name, st in sd["state"].items():
+            o, shape = self._offsets[name]
+            n = int(np.prod(shape))
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+
+
+class TVFModel:
+    """Host mirror of the reference's TVFModel (rl/models.py:511-856) for the PPO path: owns
+    `policy_net` (and, for `architecture='single'`, `value_net is policy_net`), exposes
+    `forward(x, output=..., policy_temperature=...) -> dict` with the reference's key aliasing
+    (:790-796) and a `state_dict` with the reference's `policy_net.` / `value_net.` prefixes."""
+
+    def __init__(self, encoder: str, encoder_args=None, input_dims=(4, 84, 84), actions: int = 6, device="cuda",
+                 architecture: str = "dual", dtype=torch.float32, use_rnd: bool = False, hidden_units: int = 512,
+                 encoder_activation_fn: str = "relu", observation_normalization=False,
+                 freeze_observation_normalization=False, tvf_fixed_head_horizons=None, tvf_fixed_head_weights=None,
+                 tvf_feature_sparsity: float = 0.0, tvf_feature_window: int = -1, head_scale: float = 1.0,
+                 value_head_names=("ext",), norm_eps: float = 1e-5, head_bias: bool = False,
+                 observation_scaling: str = "scaled"):
+        if architecture != "single":
+            raise NotImplementedError("HIP path: architecture='single' (PPO). 'dual' (DNA) is listed as next in DESIGN.md")
+        if use_rnd or observation_normalization or tvf_fixed_head_horizons is not None:
+            raise NotImplementedError("RND / observation normalisation / TVF heads are not on the HIP path yet")
+        if dtype != torch.float32:
+            raise ValueError("the reference path is float32 (rl/models.py:31-32)")
+        if observation_scaling != "scaled":
+            raise NotImplementedError("observation_scaling='scaled' only (x/255 fused into the first conv)")
+        if isinstance(encoder_args, str):
+            import ast
+            encoder_args = ast.literal_eval(encoder_args)
+        self.input_dims = tuple(input_dims)
+        self.actions = actions
+        self.device = device
+        self.dtype = dtype
+        self.architecture = architecture
+        self.encoder_name = encoder
+        self.name = "PPO-" + encoder
+        self.policy_net = DualHeadNet(encoder, input_dims, actions, hidden_units=hidden_units,
+                                      activation_fn=encoder_activation_fn, head_scale=head_scale,
+                                      value_head_names=value_head_names, head_bias=head_bias, device=device,
+                                      **(encoder_args or {}))
+        self.value_net = self.policy_net
+        self.device = self.policy_net.device
+
+    def model_size(self, trainable_only: bool = True):
+        return self.policy_net.n_parameters()
+
+    def prep_for_model(self, x):
+        """rl/models.py:824-856: accept ndarray or tensor, uint8 or float; the /255 scaling itself is fused
+        into the first convolution's load."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        if x.dtype not in (torch.uint8, torch.float32):
+            raise AssertionError("Invalid dtype {}".format(x.dtype))
+        if tuple(x.shape[1:]) != self.input_dims:
+            raise AssertionError("Invalid dims, expected {} but found {}".format((None, *self.input_dims), tuple(x.shape)))
+        return x.to(self.device, non_blocking=True).contiguous()
+
+    def forward(self, x, output: str = "default", policy_temperature: float = 1.0, include_rnd=False,
+                include_features=False, update_normalization=False, **kwargs):
+        assert output in ["default", "full", "policy", "value"]
+        out = self.policy_net.forward(self.prep_for_model(x), policy_temperature=policy_temperature)
+        result = {}
+        for k, v in out.items():
+            if k.startswith("_"):
+                continue
+            result["policy_" + k] = v
+            result["value_" + k] = v
+            result[k] = v
+        return result
+
+    __call__ = forward
+
+    def log_policy(self, x):
+        return self.forward(x, output="policy")["log_policy"].detach().cpu().numpy()
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for prefix in ("policy_net.", "value_net."):
+            for k, v in self.policy_net.state_dict().items():
+                sd[prefix + k] = v
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        pol = {k[len("policy_net."):]: v for k, v in sd.items() if k.startswith("policy_net.")}
+        self.policy_net.load_state_dict(pol, strict=strict)

@@ -1,0 +1,167 @@
+"""CPU: host-side logic — the synthetic vector env (C++ threads in libppo_amd.so, no GPU needed),
+the rl.config mirror, the drop-in `rl.*` module names, and the data-parallel helpers under a
+2-process gloo group (the N>1 path's sharding and reductions)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_synthetic_env_is_deterministic_and_thread_count_independent(hip_lib):
+    from ppo_amd.vec_env import SyntheticVecEnv
+    A, shape = 24, (4, 84, 84)
+    runs = []
+    for threads in (0, 1, 5):
+        env = SyntheticVecEnv(A, shape, 6, seed=7, p_done=0.2, threads=threads, pinned=False)
+        obs0 = env.reset().copy()
+        traj = [obs0]
+        rng = np.random.default_rng(0)
+        for _ in range(6):
+            obs, rew, done, infos = env.step(rng.integers(0, 6, A))
+            traj += [obs.copy(), rew, done, np.asarray([i["time"] for i in infos])]
+        runs.append(traj)
+        env.close()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a, b)
+    obs = runs[0][1]
+    assert obs.dtype == np.uint8 and obs.shape == (A, *shape)
+    assert 120 < obs.mean() < 135 and obs.std() > 70  # uniform[0,255]
+    assert not np.array_equal(runs[0][0], runs[0][1])
+
+
+def test_synthetic_env_statistics_skip_and_autoreset(hip_lib):
+    from ppo_amd.vec_env import SyntheticVecEnv
+    A = 512
+    env = SyntheticVecEnv(A, (2, 8, 8), 4, seed=3, p_done=0.05, threads=2, pinned=False)
+    env.reset()
+    rews, dones = [], []
+    for t in range(200):
+        _, r, d, infos = env.step(np.zeros(A, np.int32))
+        rews.append(r)
+        dones.append(d)
+    rews, dones = np.stack(rews), np.stack(dones)
+    assert abs(rews.mean()) < 0.02 and abs(rews.std() - 1) < 0.02       # N(0,1)
+    assert abs(dones.mean() - 0.05) < 0.005                               # Bernoulli(p)
+    # time counts steps since the last reset; a done step reports the finished episode's length
+    t_now = np.asarray([i["time"] for i in infos])
+    last_done = np.where(dones.any(0), 199 - np.argmax(dones[::-1], 0), -1)
+    ongoing = ~dones[-1]
+    assert np.array_equal(t_now[ongoing], (199 - last_done)[ongoing])
+    # action -1 leaves an env untouched
+    before = env.obs.copy()
+    a = np.zeros(A, np.int32)
+    a[::2] = -1
+    obs, r, d, _ = env.step(a)
+    assert np.array_equal(obs[::2], before[::2]) and not np.array_equal(obs[1::2], before[1::2])
+    assert (r[::2] == 0).all() and not d[::2].any()
+
+
+def test_synthetic_env_sharding_equals_one_big_env(hip_lib):
+    """Every value depends on the GLOBAL env index: two shards of 8 envs == envs 0..15 of one env."""
+    from ppo_amd.vec_env import SyntheticVecEnv
+    big = SyntheticVecEnv(16, (1, 4, 4), 3, seed=11, p_done=0.1, threads=0, pinned=False)
+    lo = SyntheticVecEnv(8, (1, 4, 4), 3, seed=11, p_done=0.1, env_offset=0, threads=0, pinned=False)
+    hi = SyntheticVecEnv(8, (1, 4, 4), 3, seed=11, p_done=0.1, env_offset=8, threads=0, pinned=False)
+    assert np.array_equal(big.reset(), np.concatenate([lo.reset(), hi.reset()]))
+    for _ in range(5):
+        ob, rb, db, _ = big.step(np.ones(16, np.int32))
+        ol, rl_, dl, _ = lo.step(np.ones(8, np.int32))
+        oh, rh, dh, _ = hi.step(np.ones(8, np.int32))
+        assert np.array_equal(ob, np.concatenate([ol, oh]))
+        assert np.array_equal(rb, np.concatenate([rl_, rh])) and np.array_equal(db, np.concatenate([dl, dh]))
+
+
+def test_config_mirrors_reference_flags_and_defaults():
+    from ppo_amd.config import Config
+    c = Config().setup([])
+    # rl/config.py defaults
+    assert (c.agents, c.n_steps, c.gamma, c.lambda_policy, c.lambda_value) == (256, 256, 0.999, 0.95, 0.95)
+    assert (c.ppo_epsilon, c.entropy_bonus, c.ppo_vf_coef, c.max_grad_norm) == (0.2, 0.01, 0.5, 20.0)
+    assert (c.policy_opt.lr, c.policy_opt.adam_epsilon, c.policy_opt.epochs, c.policy_opt.mini_batch_size) == (2.5e-4, 1e-5, 2, 256)
+    assert c.model.head_scale == 0.1 and c.model.head_bias is True and c.model.architecture == "dual"
+    assert c.batch_size == 65536 and c.tvf_return_n_step == 20
+    c = Config().setup(["--agents=8", "--model_architecture=single", "--policy_opt_lr=1e-3", "--env_embed_time=False",
+                        "--upload_batch", "--replay_size=5"])
+    assert c.agents == 8 and c.policy_opt.lr == 1e-3 and c.env.embed_time is False and c.upload_batch is True
+    assert c._ignored == ["--replay_size=5"]
+    with pytest.raises(ValueError):
+        Config().setup(["--model_architecture=triple"])
+    with pytest.raises(ValueError):
+        Config().setup(["--grad_clip_mode=banana"])
+
+
+def test_drop_in_module_names_resolve():
+    import rl.config
+    import rl.logger
+    import rl.returns
+    from ppo_amd import returns
+    assert rl.returns.gae is returns.gae and rl.returns.td_lambda is returns.td_lambda
+    assert rl.returns.calculate_bootstrapped_returns is returns.calculate_bootstrapped_returns
+    assert hasattr(rl.config, "args") and hasattr(rl.logger, "Logger")
+    src = open(os.path.join(ROOT, "rl", "rollout.py")).read() + open(os.path.join(ROOT, "rl", "ppo.py")).read()
+    assert "ppo_amd.rollout" in src and "ppo_amd.ppo" in src
+
+
+def test_product_code_never_imports_the_oracle():
+    for d, _, files in os.walk(os.path.join(ROOT, "ppo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(d, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+    for f in ("train.py",):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from ppo_amd import parallel
+from ppo_amd.vec_env import SyntheticVecEnv
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+w, r = parallel.world_size(), parallel.rank()
+assert w == 2
+# env sharding: this rank's block of the global env set
+off, n = parallel.shard(6)
+assert off == r * 6 and n == 6
+env = SyntheticVecEnv(n, (1, 4, 4), 3, seed=5, p_done=0.1, env_offset=off, threads=0, pinned=False)
+big = SyntheticVecEnv(12, (1, 4, 4), 3, seed=5, p_done=0.1, threads=0, pinned=False)
+assert np.array_equal(env.reset(), big.reset()[off:off + n])
+o, rew, d, _ = env.step(np.zeros(n, np.int32)); ob, rb, db, _ = big.step(np.zeros(12, np.int32))
+assert np.array_equal(o, ob[off:off + n]) and np.array_equal(rew, rb[off:off + n])
+# advantage moments: all-reduced {sum, sumsq, n} give the GLOBAL mean / variance
+rng = np.random.default_rng(0); full = rng.normal(2.0, 3.0, size=(16, 12)).astype(np.float32)
+mine = full[:, off:off + n].astype(np.float64)
+m = torch.tensor([mine.sum(), (mine ** 2).sum(), mine.size], dtype=torch.float64)
+parallel.allreduce_sum_(m)
+mean, var = parallel.mean_var_from_moments(m)
+assert abs(mean - full.astype(np.float64).mean()) < 1e-12 and abs(var - full.astype(np.float64).var()) < 1e-10
+# gradient exchange: sum over ranks, divided by world inside the optimiser == mean gradient
+g = torch.full((1000,), float(r + 1)); parallel.allreduce_sum_(g)
+assert torch.equal(g / w, torch.full((1000,), 1.5))
+# the global minibatch flag is split across ranks
+assert parallel.local_minibatch(256) == 128
+try:
+    parallel.local_minibatch(255); raise SystemExit("expected ValueError")
+except ValueError:
+    pass
+dist.barrier(); dist.destroy_process_group()
+print("rank", r, "ok")
+'''
+
+
+def test_data_parallel_helpers_two_ranks_gloo(hip_lib, tmp_path):
+    script = tmp_path / "gloo_worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o

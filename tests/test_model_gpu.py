@@ -121,9 +121,9 @@ def test_ppo_update_matches_reference_runner(gold):
 
 def test_backward_is_exact_given_shared_kinks(gold):
     """Full backward vs float64 autograd of the same function with the ReLU masks and max-pool
-    selections fixed to the HIP forward's own (tests/torch_replica.forward_shared_kinks): isolates
+    selections fixed to the HIP forward's own (oracle/model_torch.forward_shared_kinks): isolates
     kernel arithmetic from kink flips.  Bar: 1e-5 of each gradient's max."""
-    import torch_replica as R
+    from oracle import model_torch as R
     g, meta = gold
     net = make_net(meta)
     x = torch.from_numpy(g["mb1_prev_state"]).cuda()

@@ -196,7 +196,7 @@ def test_policy_act_log_softmax_gumbel_and_greedy(nA):
     lp = torch.empty(B, nA, device=DEV)
     act = torch.empty(B, dtype=torch.int32, device=DEV)
     lpa = torch.empty(B, device=DEV)
-    _lib.check(lib.ppo_policy_act_f32(_p(heads), B, ldo, nA, 1.0, _p(u), 0, 0, 0, _p(lp), _p(act), _p(lpa), _st()), "act")
+    _lib.check(lib.ppo_policy_act_f32(_p(heads), B, ldo, nA, 1.0, _p(u), 0, 0, 0, _p(lp), _p(act), _p(lpa), None, None, 1, _st()), "act")
     ref_lp = F.log_softmax(heads[:, :nA], dim=1)
     assert _close(lp, ref_lp, 1e-5)
     scores = ref_lp - torch.log(-torch.log(u))
@@ -207,7 +207,7 @@ def test_policy_act_log_softmax_gumbel_and_greedy(nA):
     assert _close(lpa, ref_lp.gather(1, act.long()[:, None])[:, 0], 1e-5)
     # greedy: exact argmax of the raw logits, first index on ties
     heads[0, :nA] = 1.0
-    _lib.check(lib.ppo_policy_act_f32(_p(heads), B, ldo, nA, 1.0, None, 0, 0, 1, None, _p(act), None, _st()), "act")
+    _lib.check(lib.ppo_policy_act_f32(_p(heads), B, ldo, nA, 1.0, None, 0, 0, 1, None, _p(act), None, None, None, 1, _st()), "act")
     assert torch.equal(act.long(), heads[:, :nA].argmax(1))
     assert act[0].item() == 0
     # internal generator: actions follow the policy distribution (chi-square-ish sanity), seeds differ
@@ -215,8 +215,8 @@ def test_policy_act_log_softmax_gumbel_and_greedy(nA):
     hb[:, :nA] = torch.linspace(0, 1.5, nA, device=DEV)
     a1 = torch.empty(20000, dtype=torch.int32, device=DEV)
     a2 = torch.empty_like(a1)
-    _lib.check(lib.ppo_policy_act_f32(_p(hb), 20000, ldo, nA, 1.0, None, 123, 0, 0, None, _p(a1), None, _st()), "act")
-    _lib.check(lib.ppo_policy_act_f32(_p(hb), 20000, ldo, nA, 1.0, None, 124, 0, 0, None, _p(a2), None, _st()), "act")
+    _lib.check(lib.ppo_policy_act_f32(_p(hb), 20000, ldo, nA, 1.0, None, 123, 0, 0, None, _p(a1), None, None, None, 1, _st()), "act")
+    _lib.check(lib.ppo_policy_act_f32(_p(hb), 20000, ldo, nA, 1.0, None, 124, 0, 0, None, _p(a2), None, None, None, 1, _st()), "act")
     freq = torch.bincount(a1.long(), minlength=nA).float() / 20000
     p = F.softmax(hb[0, :nA], dim=0)
     assert (freq - p).abs().max().item() < 0.02
@@ -252,9 +252,21 @@ def test_ppo_loss_matches_reference_formula_autograd(nA):
 
     dh = torch.full((B, ldo), float("nan"), device=DEV)
     stats = torch.empty(B, 8, device=DEV)
-    rc = lib.ppo_ppo_loss_f32(_p(heads), B, ldo, nA, vh, _p(actions.int()), _p(old_log_pac), _p(old_lp), _p(adv),
-                              _p(ret), eps, ent, vfc, loss_scale / B, _p(dh), _p(stats), _st())
+    act32 = actions.int()
+    rc = lib.ppo_ppo_loss_f32(_p(heads), B, ldo, nA, vh, _p(act32), _p(old_log_pac), _p(old_lp), _p(adv),
+                              _p(ret), eps, ent, vfc, loss_scale / B, _p(dh), _p(stats), None, _st())
     _lib.check(rc, "loss")
+    # indexed form: per-sample data stays in whole-batch order, the kernel follows the permutation
+    perm = torch.randperm(B, generator=g).to(DEV)
+    inv = torch.argsort(perm)
+    dh2 = torch.empty_like(dh)
+    # row perm[b] of the big arrays holds sample b (named tensors: raw pointers must outlive the launch)
+    b_act, b_lpac, b_lp, b_adv, b_ret = (t[inv].contiguous() for t in (actions.int(), old_log_pac, old_lp, adv, ret))
+    perm32 = perm.int()
+    rc = lib.ppo_ppo_loss_f32(_p(heads), B, ldo, nA, vh, _p(b_act), _p(b_lpac), _p(b_lp), _p(b_adv), _p(b_ret), eps, ent,
+                              vfc, loss_scale / B, _p(dh2), None, _p(perm32), _st())
+    _lib.check(rc, "loss indexed")
+    assert torch.equal(dh, dh2)
     assert (dh - heads.grad).abs().max().item() <= 1e-5 * heads.grad.abs().max().item() + 1e-9
     assert _close(stats[:, 0], loss_clip.detach(), 1e-5)
     assert _close(stats[:, 1], entropy.detach(), 1e-5)

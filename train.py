@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Entry point, drop-in for the reference's train.py (`python train.py --flag=value ...`,
+train.py:86-210): parse rl.config flags, pick the device, seed, build the model, run ppo.train.
+
+One process per GPU.  Single GPU: `python train.py ...`.  N GPUs of one node:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 train.py ...`
+(`--agents` is then the per-rank env count; gradients are all-reduced over RCCL).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ppo_amd import envs, logger, models, ppo  # noqa: E402
+from ppo_amd.config import args  # noqa: E402
+
+
+def make_model(log):
+    """train.py:33-82 of the reference: model from the env's spaces and the model flags."""
+    obs_shape, n_actions = envs.get_env_spec()
+    return models.TVFModel(
+        encoder=args.model.encoder, encoder_args=args.model.encoder_args, input_dims=obs_shape, actions=n_actions,
+        device=args.device, architecture=args.model.architecture, dtype=torch.float32,
+        hidden_units=args.model.hidden_units, encoder_activation_fn="relu", head_scale=args.model.head_scale,
+        head_bias=args.model.head_bias, value_head_names=("ext",))
+
+
+def main():
+    args.setup()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py: no HIP device visible; this build has no CPU path")
+    torch.cuda.set_device(local)
+    args.device = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    log = logger.Logger(quiet=(int(os.environ.get("RANK", "0")) != 0))
+    if args._ignored:
+        log.warn(f"ignoring flags of subsystems outside the PPO hot path: {args._ignored}")
+    if args.seed >= 0:  # train.py:157-163
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed + int(os.environ.get("RANK", "0")))
+    os.makedirs(args.log_folder, exist_ok=True)
+    model = make_model(log)
+    try:
+        ppo.train(model, log)
+    finally:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
