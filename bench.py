@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--scan-envs", type=int, default=1 << 20, help="A of the bandwidth-regime scan")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-scan", action="store_true")
+    p.add_argument("--scan-only", action="store_true",
+                   help="only the gae_scan section (used for the rocprofv3 --pmc passes: counter collection "
+                        "around the full PPO iteration segfaults inside rocprofv3 on this pool)")
     return p.parse_args()
 
 
@@ -209,6 +212,9 @@ def main():
     from ppo_amd.config import args
     lib = _lib.load()
     N, A = a.n_steps, a.agents
+    if a.scan_only:
+        print(json.dumps({"gae_scan": bench_scan(lib, N, a.scan_envs, A)}), flush=True)
+        return
     mb = 256
     args.setup([f"--agents={A}", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala",
                 "--env_type=synthetic", "--env_embed_time=False", "--seed=1", f"--device=cuda:{local}",

@@ -18,12 +18,11 @@
 // 16x16 accumulators; every operand read is a conflict-free ds_read_b32 at a
 // compile-time offset from a per-lane base (plane stride = 16 mod 32 banks).
 #include "common.h"
+#include "conv_stage.h"
 #include "mfma.h"
 
 namespace ppo {
 namespace {
-
-enum { IN_NONE = 0, IN_RELU = 1, IN_U8 = 2 };
 
 template <int CIN, int COUT, int H, int W, int TR>
 struct ConvCfg {
@@ -61,17 +60,27 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(
     const int g = lane >> 4;
 
     // ---- weights -> LDS, once per workgroup: s_w[((k >> 1) * COUTP + co) * 2 + (k & 1)]
-    for (int idx = tid; idx < C::K * C::COUTP; idx += 256) {
-        const int k = idx / C::COUTP;
-        const int co = idx % C::COUTP;
-        const int tap = k / C::CINP;
-        const int ci = k % C::CINP;
-        float val = 0.f;
-        if (ci < CIN && co < COUT) {
-            val = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
-                             : w[((size_t)co * CIN + ci) * 9 + tap];
+    // (8 independent loads in flight per thread, then the LDS stores: see conv_stage.h)
+    for (int base = 0; base < C::K * C::COUTP; base += 256 * 8) {
+        float v[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int k = idx / C::COUTP;
+            const int co = idx % C::COUTP;
+            const int tap = k / C::CINP;
+            const int ci = k % C::CINP;
+            off[u] = idx < C::K * C::COUTP ? ((k >> 1) * C::COUTP + co) * 2 + (k & 1) : -1;
+            v[u] = 0.f;
+            if (idx < C::K * C::COUTP && ci < CIN && co < COUT) {
+                v[u] = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
+                                  : w[((size_t)co * CIN + ci) * 9 + tap];
+            }
         }
-        s_w[((k >> 1) * C::COUTP + co) * 2 + (k & 1)] = val;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (off[u] >= 0) s_w[off[u]] = v[u];
     }
 
     const int n_items = n_images * C::NBANDS;
@@ -82,25 +91,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(
 
         __syncthreads();  // previous item's readers are done with s_in (and s_w is complete)
         // ---- input band (+halo) -> LDS with the fused input transform
-        for (int idx = tid; idx < C::CINP * C::ROWS * C::PW; idx += 256) {
-            const int ci = idx / (C::ROWS * C::PW);
-            const int rem = idx % (C::ROWS * C::PW);
-            const int r = rem / C::PW;
-            const int c = rem % C::PW;
-            const int gy = y0 + r - 1;
-            const int gx = c - 1;
-            float val = 0.f;
-            if (ci < CIN && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t gi = (((size_t)img * CIN + ci) * H + gy) * W + gx;
-                if (IN_MODE == IN_U8) {
-                    val = (float)static_cast<const uint8_t *>(in_)[gi] / 255.0f;
-                } else {
-                    val = static_cast<const float *>(in_)[gi];
-                    if (IN_MODE == IN_RELU) val = fmaxf(val, 0.f);
-                }
-            }
-            s_in[ci * C::PLANE + r * C::PW + c] = val;
-        }
+        stage_band<CIN, C::CINP, H, W, C::ROWS, C::PW, C::PLANE, 1, IN_MODE, 256>(in_, img, y0, s_in, tid);
         __syncthreads();
 
         // ---- MFMA main loop: MT pixel tiles per step of the wave

@@ -14,12 +14,11 @@
 // then writes one partial [COUT][JP] slab; conv3x3_wgrad_reduce sums the slabs in
 // a fixed order (deterministic, no atomics) into PyTorch's [o][i][3][3] layout.
 #include "common.h"
+#include "conv_stage.h"
 #include "mfma.h"
 
 namespace ppo {
 namespace {
-
-enum { IN_NONE = 0, IN_RELU = 1, IN_U8 = 2 };
 
 constexpr int pad_mod32(int v, int target) { return v + ((target - v % 32) + 32) % 32; }
 
@@ -85,35 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const void *__res
         const int y0 = (item % C::NBANDS) * TR;
 
         __syncthreads();
-        for (int idx = tid; idx < C::CINP * C::ROWS * C::PWX; idx += 256) {
-            const int ci = idx / (C::ROWS * C::PWX);
-            const int rem = idx % (C::ROWS * C::PWX);
-            const int r = rem / C::PWX;
-            const int c = rem % C::PWX;
-            const int gy = y0 + r - 1;
-            const int gx = c - 1;
-            float val = 0.f;
-            if (ci < CIN && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t gi = (((size_t)img * CIN + ci) * H + gy) * W + gx;
-                if (IN_MODE == IN_U8) {
-                    val = (float)static_cast<const uint8_t *>(in_)[gi] / 255.0f;
-                } else {
-                    val = static_cast<const float *>(in_)[gi];
-                    if (IN_MODE == IN_RELU) val = fmaxf(val, 0.f);
-                }
-            }
-            s_x[ci * C::XPLANE + r * C::PWX + c] = val;
-        }
-        for (int idx = tid; idx < COUT * TR * C::PWD; idx += 256) {
-            const int co = idx / (TR * C::PWD);
-            const int rem = idx % (TR * C::PWD);
-            const int r = rem / C::PWD;
-            const int c = rem % C::PWD;
-            const int gy = y0 + r;
-            float val = 0.f;
-            if (gy < H && c < W) val = dy[(((size_t)img * COUT + co) * H + gy) * W + c];
-            s_d[co * C::DPLANE + r * C::PWD + c] = val;
-        }
+        stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, 256>(in_, img, y0, s_x, tid);
+        stage_band<COUT, COUT, H, W, TR, C::PWD, C::DPLANE, 0, IN_NONE, 256>(dy, img, y0, s_d, tid);
         __syncthreads();
 
         // K loop over the band's pixels, 4 adjacent columns per MFMA
