@@ -6,17 +6,22 @@
 //   forward        out[n,o,y,x] = b[o] + sum_{i,ky,kx} f(in[n,i,y+ky-1,x+kx-1]) * w[o,i,ky,kx]  (+ residual)
 //   backward-data  dx[n,i,y,x]  = (sum_{o,ky,kx} dy[n,o,y-ky+1,x-kx+1] * w[o,i,ky,kx]) * [pre[n,i,y,x] > 0] (+ dres)
 // The second is the first with the weight tensor read transposed and flipped.
-// f() is the input transform fused into the LDS staging: identity, ReLU (the
-// pre-activation residual blocks of rl/impala.py:73-78 store pre-activations
-// and apply ReLU on load), or uint8 -> x/255 (rl/models.py:842-848).
+// f() is the input transform: identity, ReLU (the pre-activation residual blocks of
+// rl/impala.py:73-78 store pre-activations; ReLU is applied when the operand is read), or
+// uint8 -> x/255 (rl/models.py:842-848).
 //
-// Mapping: a 256-thread workgroup owns a band of TR output rows of one image
-// for all output channels.  The input band (+1-pixel halo, zero padded) sits in
-// LDS as planar [ci][row][col]; the weights sit in LDS as [k/2][co][2] with
-// k = tap*CINP + ci.  GEMM view: M = output channel (MFMA "i"), N = pixel
-// (MFMA "j"), K = 9*CIN.  A wave holds MT pixel tiles x NT channel tiles of
-// 16x16 accumulators; every operand read is a conflict-free ds_read_b32 at a
-// compile-time offset from a per-lane base (plane stride = 16 mod 32 banks).
+// Mapping: a 512-thread workgroup (8 waves) walks (image, band of TR output rows) items for all
+// output channels.  The input band (+1-pixel halo, zero padded) sits in LDS as planar
+// [ci][row][col] (plane stride = 16 mod 32 banks); the weights sit in LDS as [k/2][co][2] with
+// k = tap*CINP + ci.  GEMM view: M = output channel (MFMA "i"), N = pixel (MFMA "j"), K = 9*CIN.
+// A wave holds MT pixel tiles x NT channel tiles of 16x16 accumulators; every operand read is a
+// ds_read_b32 at an immediate offset from a per-lane base, software-pipelined two K steps ahead.
+//
+// Pipeline (float inputs): the band is DOUBLE-BUFFERED and filled by LDS-DMA (global_load_lds): the
+// next item's band is requested right after the barrier that publishes the current one, so HBM latency,
+// the store drain of the previous epilogue and the MFMA work of the current item overlap, with one
+// barrier per item.  (Measured before this: waves spent ~50 % of their life in s_waitcnt/s_barrier.)
+// uint8 observations (first conv only) are staged through registers with the /255 fused.
 #include "common.h"
 #include "conv_stage.h"
 #include "mfma.h"
@@ -24,7 +29,26 @@
 namespace ppo {
 namespace {
 
-template <int CIN, int COUT, int H, int W, int TR>
+constexpr int kConvWaves = 8;
+constexpr int kConvThreads = kConvWaves * 64;
+
+// Diagnostic build only (tools/conv_tune -DPPO_TUNE_STAMPS): s_memtime stamps around the phases of an
+// item, summed per phase over all waves into a buffer nothing else reads (cdna_hip_programming.md §7).
+#ifdef PPO_TUNE_STAMPS
+__device__ unsigned long long ppo_tune_stamps[8 * 8 * 1024];  // [workgroup][wave][slot], no atomics
+#define PPO_STAMP(var)                                                                                  \
+    unsigned long long var;                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                         \
+    __builtin_amdgcn_sched_barrier(0);
+#define PPO_STAMP_ADD(slot, t1, t0) \
+    if (lane == 0) ppo_tune_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + slot] += (t1) - (t0);
+#else
+#define PPO_STAMP(var)
+#define PPO_STAMP_ADD(slot, t1, t0)
+#endif
+
+template <int CIN, int COUT, int H, int W, int TR, bool DOUBLE>
 struct ConvCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;  // k-steps of 4 channels
     static constexpr int COUTP = (COUT + 15) / 16 * 16;
@@ -37,21 +61,20 @@ struct ConvCfg {
     static constexpr int NBANDS = (H + TR - 1) / TR;
     static constexpr int NPIX = TR * W;
     static constexpr int MTILES = (NPIX + 15) / 16;
-    static constexpr int LDS_IN = CINP * PLANE;  // floats
-    static constexpr int LDS_W = K * COUTP;      // floats
-    static constexpr size_t LDS_BYTES = (size_t)(LDS_IN + LDS_W) * 4;
+    static constexpr int LDS_IN = CINP * PLANE;  // floats, one band buffer
+    static constexpr int NBUF = DOUBLE ? 2 : 1;
+    static constexpr size_t LDS_BYTES = (size_t)(NBUF * LDS_IN) * 4;
 };
 
 template <int CIN, int COUT, int H, int W, int TR, int MT, int IN_MODE, bool TRANSPOSED>
-__global__ __launch_bounds__(256, 3) void conv3x3_kernel(
+__global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
     const void *__restrict__ in_, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ residual, const float *__restrict__ mask_src, float *__restrict__ out,
     int n_images)
 {
-    using C = ConvCfg<CIN, COUT, H, W, TR>;
+    constexpr bool DMA = IN_MODE != IN_U8;
+    using C = ConvCfg<CIN, COUT, H, W, TR, DMA>;
     extern __shared__ __align__(16) float smem[];
-    float *s_in = smem;
-    float *s_w = smem + C::LDS_IN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,133 +82,239 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(
     const int l15 = lane & 15;
     const int g = lane >> 4;
 
-    // ---- weights -> LDS, once per workgroup: s_w[((k >> 1) * COUTP + co) * 2 + (k & 1)]
-    // (8 independent loads in flight per thread, then the LDS stores: see conv_stage.h)
-    for (int base = 0; base < C::K * C::COUTP; base += 256 * 8) {
-        float v[8];
-        int off[8];
+    // ---- weights: the MFMA A operand of K step s is the same for every pixel tile, so each lane keeps
+    // its A values for ALL steps in registers for the lifetime of the workgroup (NT * KS VGPRs: 36 for
+    // 16->16, 144 for 32->32) — loaded once, all requests in flight together; the weights (<= 36 KB)
+    // are L1/L2-resident.  No weight image in LDS, no LDS reads for A, no staging barrier.
+    constexpr int KS = 9 * (C::CINP / 4);
+    float wa[C::NT][KS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256 + tid;
-            const int k = idx / C::COUTP;
-            const int co = idx % C::COUTP;
-            const int tap = k / C::CINP;
-            const int ci = k % C::CINP;
-            off[u] = idx < C::K * C::COUTP ? ((k >> 1) * C::COUTP + co) * 2 + (k & 1) : -1;
-            v[u] = 0.f;
-            if (idx < C::K * C::COUTP && ci < CIN && co < COUT) {
-                v[u] = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
-                                  : w[((size_t)co * CIN + ci) * 9 + tap];
-            }
+    for (int s = 0; s < KS; ++s) {
+        const int tap = s / (C::CINP / 4);
+        const int ci = (s % (C::CINP / 4)) * 4 + g;  // this lane group contracts k = 4s + g
+#pragma unroll
+        for (int n = 0; n < C::NT; ++n) {
+            const int co = n * 16 + l15;
+            float v = 0.f;
+            if (ci < CIN && co < COUT)
+                v = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
+                               : w[((size_t)co * CIN + ci) * 9 + tap];
+            wa[n][s] = v;
         }
+    }
+    // this lane's bias values (channels n*16 + g*4 + r), loaded once
+    float bias_r[C::NT][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (off[u] >= 0) s_w[off[u]] = v[u];
+    for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = n * 16 + g * 4 + r;
+            bias_r[n][r] = (bias && co < COUT) ? bias[co] : 0.f;
+        }
+    if constexpr (DMA) {
+        zero_lds<C::NBUF * C::LDS_IN, kConvThreads>(smem, tid);  // halo columns + padded channels stay zero
+        __syncthreads();
     }
 
     const int n_items = n_images * C::NBANDS;
+    auto stage = [&](int item, float *dst) {
+        const int img = item / C::NBANDS;
+        const int y0 = (item % C::NBANDS) * TR;
+        if constexpr (DMA)
+            stage_band_dma<CIN, H, W, C::ROWS, C::PW, C::PLANE, 1, kConvWaves>(static_cast<const float *>(in_), img, y0, dst, tid);
+        else
+            stage_band<CIN, C::CINP, H, W, C::ROWS, C::PW, C::PLANE, 1, IN_MODE, kConvWaves>(in_, img, y0, dst, tid);
+    };
+    if (DMA && (int)blockIdx.x < n_items) stage(blockIdx.x, smem);
+
+    // ---- per-lane constants of this wave's pixel-tile groups (identical for every item)
+    constexpr int GROUPS = (C::MTILES + MT - 1) / MT;
+    constexpr int NGW = (GROUPS + kConvWaves - 1) / kConvWaves;  // group slots per wave
+    int pix[NGW][MT];   // pixel index inside the band = its offset inside a channel plane of the band
+    int lofs[NGW][MT];  // LDS offset of the pixel's 3x3 window origin (+ this lane group's channel plane)
+#pragma unroll
+    for (int q = 0; q < NGW; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int p = ((wave + q * kConvWaves) * MT + m) * 16 + l15;
+            pix[q][m] = p;
+            const int pc = p < C::NPIX ? p : 0;
+            lofs[q][m] = (pc / W) * C::PW + (pc % W) + g * C::PLANE;
+        }
+
+    // results of the last group a wave computed are STORED one barrier later (after the next item's
+    // barrier, before its DMA request): the barrier's vmcnt(0) then only ever waits for memory
+    // operations that were issued a whole item ago, never for stores it has just issued.
+    float pend[MT][C::NT][4];
+    int pend_off[MT];
+    bool pend_live[MT];
+    float *pend_base = out;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pend_live[m] = false;
+    auto flush = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (pend_live[m]) {
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = n * 16 + g * 4 + r;
+                        if (co < COUT) {
+#ifdef PPO_TUNE_NO_STORE  // tools/conv_tune ablation build only: keep the value alive, skip the store
+                            asm volatile("" ::"v"(pend[m][n][r]));
+#else
+                            pend_base[pend_off[m] + co * (H * W)] = pend[m][n][r];
+#endif
+                        }
+                    }
+                pend_live[m] = false;
+            }
+    };
+
+    int buf = 0;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int img = item / C::NBANDS;
-        const int band = item % C::NBANDS;
-        const int y0 = band * TR;
+        const int y0 = (item % C::NBANDS) * TR;
+        const int plim = min(C::NPIX, (H - y0) * W);  // pixels of this band that exist in the image
+        const size_t img_off = (size_t)img * COUT * H * W + (size_t)y0 * W;
+        float *s_in = smem + buf * C::LDS_IN;
+        PPO_STAMP(t_top)
+        if constexpr (DMA) {
+            __syncthreads();  // this item's band has landed (vmcnt(0)) and every wave is done with the other buffer
+            flush();
+#ifndef PPO_TUNE_NO_STAGE  // tools/conv_tune ablation build only
+            if (item + (int)gridDim.x < n_items) stage(item + gridDim.x, smem + (buf ^ 1) * C::LDS_IN);
+#endif
+        } else {
+            __syncthreads();  // previous item's readers are done with s_in
+            flush();
+            stage(item, s_in);
+            __syncthreads();
+        }
+        PPO_STAMP(t_staged)
+        PPO_STAMP_ADD(0, t_staged, t_top)  // barrier + staging issue
 
-        __syncthreads();  // previous item's readers are done with s_in (and s_w is complete)
-        // ---- input band (+halo) -> LDS with the fused input transform
-        stage_band<CIN, C::CINP, H, W, C::ROWS, C::PW, C::PLANE, 1, IN_MODE, 256>(in_, img, y0, s_in, tid);
-        __syncthreads();
-
-        // ---- MFMA main loop: MT pixel tiles per step of the wave
-        constexpr int GROUPS = (C::MTILES + MT - 1) / MT;
-        constexpr int TAP_UNROLL = C::CINP >= 16 ? 1 : 9;
-        for (int grp = wave; grp < GROUPS; grp += 4) {
-            int pix[MT];
-            int base[MT];
+        // ---- MFMA main loop: MT pixel tiles per group
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int p = (grp * MT + m) * 16 + l15;
-                pix[m] = p;
-                const int pc = p < C::NPIX ? p : 0;
-                base[m] = (pc / W) * C::PW + (pc % W) + g * C::PLANE;
-            }
+        for (int q = 0; q < NGW; ++q) {
+            if (wave + q * kConvWaves >= GROUPS) break;
+            PPO_STAMP(t_g0)
+            flush();  // an earlier group of this item (NGW > 1)
             f32x4 acc[C::NT][MT];
 #pragma unroll
             for (int n = 0; n < C::NT; ++n)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-            // big-CIN layers: keep the tap loop rolled so the compiler cannot hoist all
-            // 9*CIN/4 steps of LDS reads at once (it spills otherwise)
-#pragma unroll TAP_UNROLL
-            for (int tap = 0; tap < 9; ++tap) {
-                const int tap_off = (tap / 3) * C::PW + (tap % 3);
-#pragma unroll
-                for (int cs = 0; cs < C::CINP / 4; ++cs) {
-                    const int k0 = tap * C::CINP + cs * 4;  // this lane group contracts k = k0 + g
-                    float a[C::NT], b[MT];
-#pragma unroll
-                    for (int n = 0; n < C::NT; ++n)
-                        a[n] = s_w[(((k0 >> 1) + (g >> 1)) * C::COUTP + n * 16 + l15) * 2 + (g & 1)];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) b[m] = s_in[base[m] + cs * 4 * C::PLANE + tap_off];
-#pragma unroll
-                    for (int n = 0; n < C::NT; ++n)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) acc[n][m] = mfma16(a[n], b[m], acc[n][m]);
-                }
-            }
-
-            // ---- epilogue: lane holds pixel (lane & 15) x channels g*4 .. g*4+3 of each tile
+            // epilogue operands (ReLU gate source, residual) are requested NOW and consumed after the K
+            // loop, so their memory latency hides under the MFMAs
+            bool live[MT];
+            float gate[MT][C::NT][4], res[MT][C::NT][4];
+            const float *mask_img = mask_src ? mask_src + img_off : nullptr;
+            const float *res_img = residual ? residual + img_off : nullptr;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int p = pix[m];
-                const int y = y0 + p / W;
-                const int x = p % W;
-                if (p < C::NPIX && y < H) {
+                live[m] = pix[q][m] < plim;
 #pragma unroll
-                    for (int n = 0; n < C::NT; ++n) {
+                for (int n = 0; n < C::NT; ++n)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int co = n * 16 + g * 4 + r;
-                            if (co < COUT) {
-                                const size_t oi = (((size_t)img * COUT + co) * H + y) * W + x;
-                                float val = acc[n][m][r];
-                                if (bias) val += bias[co];
-                                if (mask_src) val = mask_src[oi] > 0.f ? val : 0.f;
-                                if (residual) val += residual[oi];
-                                out[oi] = val;
-                            }
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = n * 16 + g * 4 + r;
+                        const int oi = pix[q][m] + co * (H * W);
+                        gate[m][n][r] = (mask_img && live[m] && co < COUT) ? mask_img[oi] : 1.f;
+                        res[m][n][r] = (res_img && live[m] && co < COUT) ? res_img[oi] : 0.f;
                     }
+            }
+            int base[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) base[m] = lofs[q][m] + buf * C::LDS_IN;
+
+            PPO_STAMP(t_g1)
+            PPO_STAMP_ADD(1, t_g1, t_g0)  // group prologue (gate/residual requests)
+            // K loop, fully unrolled (every LDS offset is an immediate) and software-pipelined by hand:
+            // the operands of step s+PF are requested before the MFMAs of step s issue, and a
+            // sched_barrier per step keeps the compiler from re-batching the reads (left alone it either
+            // waits on each step's reads right before its MFMAs, or hoists all of them and spills).
+            constexpr int PF = 2;
+            float b[PF + 1][MT];
+            auto load_step = [&](int s, float (&bb)[MT]) {
+                const int tap = s / (C::CINP / 4);
+                const int cs = s % (C::CINP / 4);
+                const int tap_off = (tap / 3) * C::PW + (tap % 3);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) bb[m] = smem[base[m] + cs * 4 * C::PLANE + tap_off];
+            };
+#pragma unroll
+            for (int s = 0; s < PF; ++s) load_step(s, b[s]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + PF < KS) load_step(s + PF, b[(s + PF) % (PF + 1)]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float bv = b[s % (PF + 1)][m];
+                    if (IN_MODE == IN_RELU) bv = relu1(bv);  // pre-activation input: ReLU on read
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) acc[n][m] = mfma16(wa[n][s], bv, acc[n][m]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            PPO_STAMP(t_g2)
+            PPO_STAMP_ADD(2, t_g2, t_g1)  // K loop
+
+            // ---- epilogue: lane holds pixel (lane & 15) x channels g*4 .. g*4+3 of each tile; the values
+            // are parked in registers and written by the next flush()
+            pend_base = out + img_off;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                pend_live[m] = live[m];
+                pend_off[m] = pix[q][m];
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float val = acc[n][m][r] + bias_r[n][r];
+                        val = gate[m][n][r] > 0.f ? val : 0.f;
+                        pend[m][n][r] = val + res[m][n][r];
+                    }
             }
         }
+        PPO_STAMP(t_end)
+        PPO_STAMP_ADD(3, t_end, t_staged)  // whole compute section of the item (all groups + epilogues)
+        PPO_STAMP_ADD(4, t_end, t_top)     // whole item
+        if (lane == 0) { PPO_STAMP_ADD(5, 1ull, 0ull) }  // item-waves counted
+        if constexpr (DMA) buf ^= 1;
     }
+    flush();
 }
 
 template <int CIN, int COUT, int H, int W, int TR, int MT, int IN_MODE, bool TRANSPOSED>
 int launch_conv(const void *in, const float *w, const float *bias, const float *residual,
                 const float *mask_src, float *out, int n_images, hipStream_t st)
 {
-    using C = ConvCfg<CIN, COUT, H, W, TR>;
+    using C = ConvCfg<CIN, COUT, H, W, TR, IN_MODE != IN_U8>;
     auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, IN_MODE, TRANSPOSED>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int wg_per_cu = 0;  // resident workgroups per CU (LDS- and VGPR-limited), queried once
+    if (wg_per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kConvThreads, C::LDS_BYTES);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3: occupancy query: %s", hipGetErrorString(e));
+        wg_per_cu = nb < 1 ? 1 : (nb > 3 ? 3 : nb);
     }
     const int n_items = n_images * C::NBANDS;
-    const int wg_per_cu = (int)((160 * 1024) / C::LDS_BYTES) > 4 ? 4 : (int)((160 * 1024) / C::LDS_BYTES);
-    int grid = 256 * (wg_per_cu < 1 ? 1 : wg_per_cu);
+    int grid = 256 * wg_per_cu;
     if (grid > n_items) grid = n_items;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, in, w, bias, residual, mask_src, out,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kConvThreads), C::LDS_BYTES, st, in, w, bias, residual, mask_src, out,
                        n_images);
     return check_launch("conv3x3_kernel");
 }
 
 // Supported layer geometries: Atari 84x84 (rl/atari.py) and Procgen 64x64 (rl/procgen.py)
 // through the three IMPALA stacks (16, 32, 32 channels; rl/models.py:873).
+// TR / MT are chosen so that the pixel-tile groups of a band divide evenly over the 8 waves.
 template <int IN_MODE, bool TRANSPOSED>
 int dispatch_conv(int cin, int cout, int h, int w_, const void *in, const float *w, const float *bias,
                   const float *residual, const float *mask_src, float *out, int n, hipStream_t st)
@@ -202,20 +331,20 @@ int dispatch_conv(int cin, int cout, int h, int w_, const void *in, const float 
     constexpr bool UP = !TRANSPOSED && IN_MODE == IN_NONE;
     constexpr bool DOWN = TRANSPOSED;
     constexpr bool SAME = IN_MODE != IN_U8;
-    PPO_CONV_CASE(FIRST, 4, 16, 84, 84, 12, 2)
-    PPO_CONV_CASE(FIRST, 5, 16, 84, 84, 12, 2)
-    PPO_CONV_CASE(FIRST, 3, 16, 64, 64, 16, 2)
-    PPO_CONV_CASE(FIRST, 4, 16, 64, 64, 16, 2)
-    PPO_CONV_CASE(UP, 16, 32, 42, 42, 14, 2)
-    PPO_CONV_CASE(UP, 16, 32, 32, 32, 16, 2)
-    PPO_CONV_CASE(DOWN, 32, 16, 42, 42, 14, 2)
-    PPO_CONV_CASE(DOWN, 32, 16, 32, 32, 16, 2)
-    PPO_CONV_CASE(SAME, 16, 16, 42, 42, 14, 2)
-    PPO_CONV_CASE(SAME, 16, 16, 32, 32, 16, 2)
-    PPO_CONV_CASE(SAME, 32, 32, 21, 21, 11, 2)
-    PPO_CONV_CASE(SAME, 32, 32, 16, 16, 16, 2)
-    PPO_CONV_CASE(SAME, 32, 32, 11, 11, 11, 2)
-    PPO_CONV_CASE(SAME, 32, 32, 8, 8, 8, 2)
+    PPO_CONV_CASE(FIRST, 4, 16, 84, 84, 12, 4)   // 63 tiles -> 16 groups of 4: 2 per wave
+    PPO_CONV_CASE(FIRST, 5, 16, 84, 84, 12, 4)
+    PPO_CONV_CASE(FIRST, 3, 16, 64, 64, 16, 4)   // 64 tiles -> 16 groups
+    PPO_CONV_CASE(FIRST, 4, 16, 64, 64, 16, 4)
+    PPO_CONV_CASE(UP, 16, 32, 42, 42, 6, 2)      // 252 px = 16 tiles -> 8 groups of 2: 1 per wave
+    PPO_CONV_CASE(UP, 16, 32, 32, 32, 8, 2)      // 256 px = 16 tiles
+    PPO_CONV_CASE(DOWN, 32, 16, 42, 42, 6, 2)
+    PPO_CONV_CASE(DOWN, 32, 16, 32, 32, 8, 2)
+    PPO_CONV_CASE(SAME, 16, 16, 42, 42, 6, 2)
+    PPO_CONV_CASE(SAME, 16, 16, 32, 32, 8, 2)
+    PPO_CONV_CASE(SAME, 32, 32, 21, 21, 6, 1)    // 126 px = 8 tiles: 1 per wave
+    PPO_CONV_CASE(SAME, 32, 32, 16, 16, 8, 1)    // 128 px = 8 tiles
+    PPO_CONV_CASE(SAME, 32, 32, 11, 11, 11, 1)   // 121 px = 8 tiles
+    PPO_CONV_CASE(SAME, 32, 32, 8, 8, 8, 1)      // 64 px = 4 tiles (half the waves idle: tiny layer)
 #undef PPO_CONV_CASE
     return fail(PPO_E_INVALID, "conv3x3: unsupported geometry cin=%d cout=%d h=%d w=%d transposed=%d", cin,
                 cout, h, w_, (int)TRANSPOSED);

@@ -2,17 +2,23 @@
 //
 //   dW[o,i,ky,kx] = sum_{n,y,x} dy[n,o,y,x] * f(in[n,i,y+ky-1,x+kx-1])      db[o] = sum_{n,y,x} dy[n,o,y,x]
 //
-// (what autograd computes for torch.nn.Conv2d at rl/impala.py:61-62,96; f is the
-// same fused load transform as the forward kernel: identity / ReLU / uint8/255).
+// (what autograd computes for torch.nn.Conv2d at rl/impala.py:61-62,96; f is the same fused load
+// transform as the forward kernel: identity / ReLU / uint8/255).
 //
-// GEMM view: M = output channel o (MFMA "i", operand A = dy), N = j = tap*CINP + i
-// plus one all-ones column whose result is db (MFMA "j", operand B = shifted input),
-// K = pixels.  A 256-thread workgroup walks (image, row band) items; both bands sit
-// in LDS (planar, plane stride = 2 mod 32 banks so that 16 channels x 2 adjacent
-// pixels are conflict-free); the four waves split the N tiles and keep their
-// accumulators in registers across all items of the workgroup.  Each workgroup
-// then writes one partial [COUT][JP] slab; conv3x3_wgrad_reduce sums the slabs in
-// a fixed order (deterministic, no atomics) into PyTorch's [o][i][3][3] layout.
+// GEMM view: M = output channel o (MFMA "i", operand A = dy), N = j = tap*CINP + i plus one all-ones
+// column whose result is db (MFMA "j", operand B = shifted input), K = pixels, 4 adjacent pixels of a
+// row per v_mfma_f32_16x16x4_f32.
+//
+// A 512-thread workgroup (8 waves) walks (image, row band) items.  Both bands sit in LDS, planar, plane
+// stride = 2 (mod 32) banks so that 16 channels x 2 adjacent pixels are conflict-free; two extra planes
+// hold 1.0 (the bias column) and 0.0 (padding columns), so the K loop has no selects or branches
+// (the first version chose 1/0/x per lane and skipped tiles per wave: hipcc turned that into exec-masked
+// branches and accumulator copies, 30 VALU per MFMA).  wave % 4 owns a fixed set of N tiles (the wave
+// count per tile set is a compile-time property of the code path the wave takes), wave / 4 splits the
+// band's K steps in two contiguous halves.  Accumulators stay in registers across all items of the
+// workgroup; at the end the second K half is added through LDS and one [COUT][JP] slab per workgroup is
+// written.  conv3x3_wgrad_reduce sums the slabs in a fixed order (deterministic, no atomics) into
+// PyTorch's [o][i][3][3] layout.
 #include "common.h"
 #include "conv_stage.h"
 #include "mfma.h"
@@ -22,6 +28,9 @@ namespace {
 
 constexpr int pad_mod32(int v, int target) { return v + ((target - v % 32) + 32) % 32; }
 
+constexpr int kWgradWaves = 8;
+constexpr int kWgradKG = kWgradWaves / 4;  // K-split groups
+
 template <int CIN, int COUT, int H, int W, int TR>
 struct WgradCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;
@@ -29,23 +38,55 @@ struct WgradCfg {
     static constexpr int NJ = 9 * CINP + 1;  // + the ones column (bias gradient)
     static constexpr int NTT = (NJ + 15) / 16;
     static constexpr int JP = NTT * 16;
-    static constexpr int NTW = (NTT + 3) / 4;  // n-tiles per wave (max)
+    static constexpr int NTW_MAX = (NTT + 3) / 4;  // tiles of waves with (wave % 4) < REM
+    static constexpr int REM = NTT % 4 == 0 ? 4 : NTT % 4;
     static constexpr int PWD = (W + 3) / 4 * 4;
     static constexpr int PWX = PWD + 2;
     static constexpr int ROWS = TR + 2;
     static constexpr int XPLANE = pad_mod32(ROWS * PWX, 2);
     static constexpr int DPLANE = pad_mod32(TR * PWD, 2);
     static constexpr int NBANDS = (H + TR - 1) / TR;
-    static constexpr int LDS_X = CINP * XPLANE;
+    static constexpr int STEPS = TR * (PWD / 4);
+    static constexpr int LDS_X = (CINP + 2) * XPLANE;  // + ones plane + zeros plane
     static constexpr int LDS_D = COUT * DPLANE;
-    static constexpr size_t LDS_BYTES = (size_t)(LDS_X + LDS_D) * 4;
+    static constexpr int LDS_RED = COUT * JP;  // cross-K-group reduction image (reuses the staging space)
+    static constexpr int LDS_WORDS = (LDS_X + LDS_D) > LDS_RED ? (LDS_X + LDS_D) : LDS_RED;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_WORDS * 4;
     static_assert(COUT % 16 == 0, "COUT must be a multiple of 16");
 };
 
+// The K loop for a wave that owns NTW tiles.  Returns through acc.
+template <class C, int NTW, bool RELU>
+__device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, const float *__restrict__ s_d,
+                                             const int (&joff)[C::NTW_MAX], int aoff, int g, int s_begin, int s_end,
+                                             f32x4 (&acc)[C::MTC][C::NTW_MAX])
+{
+    constexpr int SPR = C::PWD / 4;  // steps per row
+#pragma unroll 4
+    for (int s = s_begin; s < s_end; ++s) {
+        const int r = s / SPR;               // wave-uniform
+        const int pd = 4 * s;                // dy rows are PWD = 4*SPR wide: linear in s
+        const int px = 4 * s + 2 * r + g;    // x rows are PWD + 2 wide
+        float a[C::MTC], b[NTW];
+#pragma unroll
+        for (int m = 0; m < C::MTC; ++m) a[m] = s_d[m * 16 * C::DPLANE + aoff + pd];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = s_x[joff[t] + px];
+        if (RELU) {  // the band was staged raw by LDS-DMA: the forward's ReLU-on-load is applied here
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) b[t] = relu1(b[t]);
+        }
+#pragma unroll
+        for (int m = 0; m < C::MTC; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+    }
+}
+
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const void *__restrict__ in_,
-                                                                const float *__restrict__ dy,
-                                                                float *__restrict__ partial, int n_images)
+__global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const void *__restrict__ in_,
+                                                                        const float *__restrict__ dy,
+                                                                        float *__restrict__ partial, int n_images)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR>;
     extern __shared__ __align__(16) float smem[];
@@ -55,111 +96,144 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const void *__res
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wt = wave & 3;   // owner of N tiles wt, wt+4, ...
+    const int kg = wave >> 2;  // K-split group
     const int l15 = lane & 15;
     const int g = lane >> 4;
 
-    // per-lane B offsets of this wave's n-tiles: j = (wave + 4*t)*16 + l15 -> (tap, ci)
-    int joff[C::NTW];
-    int jkind[C::NTW];  // 0: input element, 1: ones column, 2: padding (zero)
+    // per-lane B offsets of this wave's n-tiles: j = (wt + 4*t)*16 + l15 -> (tap, ci); the bias column reads
+    // the ones plane, padding columns the zeros plane
+    int joff[C::NTW_MAX];
 #pragma unroll
-    for (int t = 0; t < C::NTW; ++t) {
-        const int j = (wave + 4 * t) * 16 + l15;
+    for (int t = 0; t < C::NTW_MAX; ++t) {
+        const int j = (wt + 4 * t) * 16 + l15;
         const int tap = j / C::CINP;
         const int ci = j % C::CINP;
-        joff[t] = ci * C::XPLANE + (tap / 3) * C::PWX + (tap % 3);
-        jkind[t] = j < 9 * C::CINP ? 0 : (j == 9 * C::CINP ? 1 : 2);
-        if (jkind[t] != 0) joff[t] = 0;
+        joff[t] = j < 9 * C::CINP ? ci * C::XPLANE + (tap / 3) * C::PWX + (tap % 3)
+                                  : (j == 9 * C::CINP ? C::CINP * C::XPLANE : (C::CINP + 1) * C::XPLANE);
     }
     const int aoff = l15 * C::DPLANE + g;  // A: channel l15 of the m-tile, pixel +g
 
-    f32x4 acc[C::MTC][C::NTW];
+    f32x4 acc[C::MTC][C::NTW_MAX];
 #pragma unroll
     for (int m = 0; m < C::MTC; ++m)
 #pragma unroll
-        for (int t = 0; t < C::NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < C::NTW_MAX; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // zero everything once (halo columns, padded channels and padded dy columns are never written by the
+    // LDS-DMA staging), then the constant planes
+    zero_lds<C::LDS_X + C::LDS_D, kWgradWaves * 64>(smem, tid);
+    __syncthreads();
+    for (int i = tid; i < C::XPLANE; i += kWgradWaves * 64) s_x[C::CINP * C::XPLANE + i] = 1.0f;
+
+    const int s_begin = kg * C::STEPS / kWgradKG;
+    const int s_end = (kg + 1) * C::STEPS / kWgradKG;
     const int n_items = n_images * C::NBANDS;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
-
         __syncthreads();
-        stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, 256>(in_, img, y0, s_x, tid);
-        stage_band<COUT, COUT, H, W, TR, C::PWD, C::DPLANE, 0, IN_NONE, 256>(dy, img, y0, s_d, tid);
+        if constexpr (IN_MODE == IN_U8)
+            stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, s_x, tid);
+        else
+            stage_band_dma<CIN, H, W, C::ROWS, C::PWX, C::XPLANE, 1, kWgradWaves>(static_cast<const float *>(in_), img, y0, s_x, tid);
+        stage_band_dma<COUT, H, W, TR, C::PWD, C::DPLANE, 0, kWgradWaves>(dy, img, y0, s_d, tid);
         __syncthreads();
-
-        // K loop over the band's pixels, 4 adjacent columns per MFMA
-#pragma unroll 1
-        for (int r = 0; r < TR; ++r) {
-#pragma unroll
-            for (int x4 = 0; x4 < C::PWD / 4; ++x4) {
-                const int pd = r * C::PWD + x4 * 4;  // dy pixel offset (lane adds g via aoff)
-                const int px = r * C::PWX + x4 * 4 + g;
-                float a[C::MTC], b[C::NTW];
-#pragma unroll
-                for (int m = 0; m < C::MTC; ++m) a[m] = s_d[m * 16 * C::DPLANE + aoff + pd];
-#pragma unroll
-                for (int t = 0; t < C::NTW; ++t) {
-                    const float xv = s_x[joff[t] + px];
-                    b[t] = jkind[t] == 0 ? xv : (jkind[t] == 1 ? 1.0f : 0.0f);
-                }
-#pragma unroll
-                for (int m = 0; m < C::MTC; ++m)
-#pragma unroll
-                    for (int t = 0; t < C::NTW; ++t)
-                        if ((wave + 4 * t) < C::NTT) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
-            }
-        }
+        constexpr bool RELU = IN_MODE == IN_RELU;
+        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU>(s_x, s_d, joff, aoff, g, s_begin, s_end, acc);
+        else if (C::NTW_MAX > 1) wgrad_k_loop<C, (C::NTW_MAX > 1 ? C::NTW_MAX - 1 : 1), RELU>(s_x, s_d, joff, aoff, g, s_begin, s_end, acc);
     }
 
-    // partial[wg][co][j]; lane holds rows g*4+r (co), column l15 (j) of each tile
-    float *slab = partial + (size_t)blockIdx.x * COUT * C::JP;
+    // fold the K groups through LDS (fixed order), then one slab per workgroup:
+    // partial[wg][co][j]; a lane holds rows g*4+r (co), column l15 (j) of each of its tiles
+    float *s_red = smem;
+#pragma unroll 1
+    for (int src = 1; src < kWgradKG; ++src) {
+        __syncthreads();
+        if (kg == src) {
 #pragma unroll
-    for (int m = 0; m < C::MTC; ++m)
+            for (int m = 0; m < C::MTC; ++m)
 #pragma unroll
-        for (int t = 0; t < C::NTW; ++t) {
-            const int nt = wave + 4 * t;
-            if (nt < C::NTT) {
+                for (int t = 0; t < C::NTW_MAX; ++t)
+                    if (wt + 4 * t < C::NTT)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(m * 16 + g * 4 + r) * C::JP + nt * 16 + l15] = acc[m][t][r];
-            }
+                        for (int r = 0; r < 4; ++r)
+                            s_red[(m * 16 + g * 4 + r) * C::JP + (wt + 4 * t) * 16 + l15] = acc[m][t][r];
         }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int m = 0; m < C::MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < C::NTW_MAX; ++t)
+                    if (wt + 4 * t < C::NTT)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[m][t][r] += s_red[(m * 16 + g * 4 + r) * C::JP + (wt + 4 * t) * 16 + l15];
+        }
+    }
+    if (kg == 0) {
+        float *slab = partial + (size_t)blockIdx.x * COUT * C::JP;
+#pragma unroll
+        for (int m = 0; m < C::MTC; ++m)
+#pragma unroll
+            for (int t = 0; t < C::NTW_MAX; ++t)
+                if (wt + 4 * t < C::NTT)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        slab[(m * 16 + g * 4 + r) * C::JP + (wt + 4 * t) * 16 + l15] = acc[m][t][r];
+    }
 }
 
-// dW[o][i][tap] = sum_wg partial[wg][o][tap*CINP + i]; db[o] = sum_wg partial[wg][o][9*CINP]
+// dW[o][i][tap] = sum_wg partial[wg][o][tap*CINP + i]; db[o] = sum_wg partial[wg][o][9*CINP].
+// 64 outputs per workgroup, 4 threads per output each summing a quarter of the slabs, combined in LDS
+// in a fixed order.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ partial, int n_slabs,
                                                                    int cout, int cin, int cinp, int jp,
                                                                    float *__restrict__ dw, float *__restrict__ db,
                                                                    int accumulate)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s[256];
     const int nj = 9 * cinp + 1;
-    if (idx >= cout * nj) return;
-    const int co = idx / nj;
-    const int j = idx % nj;
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const bool live = idx < cout * nj;
+    const int co = live ? idx / nj : 0;
+    const int j = live ? idx % nj : 0;
     const size_t stride = (size_t)cout * jp;
     const float *p = partial + (size_t)co * jp + j;
+    const int per = (n_slabs + 3) / 4;
+    const int lo = part * per;
+    const int hi = lo + per < n_slabs ? lo + per : n_slabs;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= n_slabs; s += 4) {
-        s0 += p[(size_t)(s + 0) * stride];
-        s1 += p[(size_t)(s + 1) * stride];
-        s2 += p[(size_t)(s + 2) * stride];
-        s3 += p[(size_t)(s + 3) * stride];
+    if (live) {
+        int q = lo;
+        for (; q + 4 <= hi; q += 4) {
+            s0 += p[(size_t)(q + 0) * stride];
+            s1 += p[(size_t)(q + 1) * stride];
+            s2 += p[(size_t)(q + 2) * stride];
+            s3 += p[(size_t)(q + 3) * stride];
+        }
+        for (; q < hi; ++q) s0 += p[(size_t)q * stride];
     }
-    for (; s < n_slabs; ++s) s0 += p[(size_t)s * stride];
-    const float sum = (s0 + s1) + (s2 + s3);
-    if (j == 9 * cinp) {
-        if (db) db[co] = accumulate ? db[co] + sum : sum;
-    } else {
-        const int tap = j / cinp;
-        const int ci = j % cinp;
-        if (ci < cin) {
-            float *d = dw + ((size_t)co * cin + ci) * 9 + tap;
-            *d = accumulate ? *d + sum : sum;
+    s[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part == 0 && live) {
+        const float sum = (s[threadIdx.x] + s[threadIdx.x + 64]) + (s[threadIdx.x + 128] + s[threadIdx.x + 192]);
+        if (j == 9 * cinp) {
+            if (db) db[co] = accumulate ? db[co] + sum : sum;
+        } else {
+            const int tap = j / cinp;
+            const int ci = j % cinp;
+            if (ci < cin) {
+                float *d = dw + ((size_t)co * cin + ci) * 9 + tap;
+                *d = accumulate ? *d + sum : sum;
+            }
         }
     }
 }
+
+constexpr int kWgradMaxSlabs = 512;
 
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
 int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *workspace, size_t workspace_bytes,
@@ -175,16 +249,22 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
         attr_set = true;
     }
     const int n_items = n_images * C::NBANDS;
-    int grid = n_items < 256 ? n_items : 256;
+    // as many workgroups as fit on the chip at once (LDS-limited), at most kWgradMaxSlabs slabs
+    int per_cu = (int)((160 * 1024) / C::LDS_BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    if ((size_t)COUT * C::JP * sizeof(float) > 16 * 1024) per_cu = 1;  // big slabs: keep the reduce traffic down
+    int grid = 256 * per_cu;
+    if (grid > kWgradMaxSlabs) grid = kWgradMaxSlabs;
+    if (grid > n_items) grid = n_items;
     const size_t need = (size_t)grid * COUT * C::JP * sizeof(float);
     if (need > workspace_bytes)
         return fail(PPO_E_INVALID, "conv3x3_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, in, dy, workspace, n_images);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWgradWaves * 64), C::LDS_BYTES, st, in, dy, workspace, n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
     const int total = COUT * (9 * C::CINP + 1);
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, grid,
-                       COUT, CIN, C::CINP, C::JP, dw, db, accumulate);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, grid, COUT,
+                       CIN, C::CINP, C::JP, dw, db, accumulate);
     return check_launch("conv3x3_wgrad_reduce_kernel");
 }
 
@@ -226,7 +306,7 @@ extern "C" size_t ppo_conv3x3_wgrad_workspace_bytes(int cin, int cout)
 {
     const int cinp = (cin + 3) / 4 * 4;
     const int jp = ((9 * cinp + 1) + 15) / 16 * 16;
-    return (size_t)256 * cout * jp * sizeof(float);
+    return (size_t)ppo::kWgradMaxSlabs * cout * jp * sizeof(float);
 }
 
 extern "C" int ppo_conv3x3_backward_weight_f32(const void *in, int in_mode, const float *dy, float *dweight,

@@ -1,10 +1,14 @@
 // Global -> LDS staging shared by the convolution kernels (gfx950).
 //
-// A band of image rows (+1-pixel halo, zero padded) of every input channel goes to LDS as planar
+// A band of image rows (+halo, zero padded) of every input channel goes to LDS as planar
 // [channel][row][col] with the load transform fused (identity / ReLU / uint8 -> x/255).
-// The loop is written as "U independent global loads, then U LDS stores" so that each thread keeps U
-// requests in flight: a plain load->store loop waits for every load (s_waitcnt vmcnt(0) per element)
-// and made the whole convolution latency-bound (81 us -> see profiles/ for the effect).
+//
+// Mapping: a wave-instruction covers 64/LG consecutive band rows with LG (16/32/64) lanes per row,
+// lane = column; the (channel, row-block) a wave works on is wave-uniform, so the per-element work
+// is a handful of VALU instructions (the first version decoded a flat index per element with three
+// constant divisions: ~30 VALU per element, as much VALU time as the MFMAs themselves —
+// profiles/: SQ_INSTS_VALU 8.2 per MFMA).  Loads are issued U at a time before the LDS stores so
+// that U requests per thread are in flight.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,29 +20,41 @@ enum { IN_NONE = 0, IN_RELU = 1, IN_U8 = 2 };
 
 // s_dst[c * PLANE + r * PW + col] for c < CP, r < ROWS, col < PW holds
 //   f(src[img][c][y0 + r - HALO][col - HALO])   (0 outside the image or for c >= C)
-template <int C, int CP, int H, int W, int ROWS, int PW, int PLANE, int HALO, int IN_MODE, int NTHREADS>
+template <int C, int CP, int H, int W, int ROWS, int PW, int PLANE, int HALO, int IN_MODE, int NWAVES>
 __device__ __forceinline__ void stage_band(const void *__restrict__ src_, int img, int y0, float *__restrict__ s_dst,
                                            int tid)
 {
-    constexpr int TOTAL = CP * ROWS * PW;
+    constexpr int LG = PW <= 16 ? 16 : (PW <= 32 ? 32 : 64);
+    constexpr int RPI = 64 / LG;               // band rows per wave-instruction
+    constexpr int NPASS = (PW + 63) / 64;      // column passes (> 1 only for PW > 64)
+    constexpr int RSTEP = NWAVES * RPI;        // band rows per workgroup step
+    constexpr int RB = (ROWS + RSTEP - 1) / RSTEP;
+    constexpr int Q = CP * RB * NPASS;         // wave-uniform work items
     constexpr int U = 8;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int sub = lane / LG;
+    const int col0 = lane % LG;
+    const int rw = wave * RPI + sub;  // this lane's row inside a row block
 #pragma unroll 1
-    for (int base = 0; base < TOTAL; base += NTHREADS * U) {
+    for (int q0 = 0; q0 < Q; q0 += U) {
         float v[U];
         int off[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int idx = base + u * NTHREADS + tid;
-            const int c = idx / (ROWS * PW);
-            const int rem = idx - c * (ROWS * PW);
-            const int r = rem / PW;
-            const int col = rem - r * PW;
+            const int q = q0 + u;  // wave-uniform
+            const int pass = q % NPASS;
+            const int qq = q / NPASS;
+            const int c = qq / RB;
+            const int r = (qq % RB) * RSTEP + rw;
+            const int col = col0 + 64 * pass;
+            const bool in_lds = q < Q && r < ROWS && col < PW;
             const int gy = y0 + r - HALO;
             const int gx = col - HALO;
-            off[u] = idx < TOTAL ? c * PLANE + r * PW + col : -1;
+            off[u] = in_lds ? c * PLANE + r * PW + col : -1;
             v[u] = 0.f;
-            if (idx < TOTAL && c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t gi = (((size_t)img * C + c) * H + gy) * W + gx;
+            if (in_lds && c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t gi = ((size_t)(img * C + c) * H + gy) * W + gx;
                 if (IN_MODE == IN_U8) v[u] = (float)static_cast<const uint8_t *>(src_)[gi];
                 else v[u] = static_cast<const float *>(src_)[gi];
             }
@@ -53,6 +69,57 @@ __device__ __forceinline__ void stage_band(const void *__restrict__ src_, int im
             }
         }
     }
+}
+
+// LDS-DMA variant for float32 sources (no fused transform: consumers apply ReLU when they read the
+// operand).  One `global_load_lds_dword` per band row and wave: the data goes HBM -> LDS without passing
+// through VGPRs, so a wave can have ALL its rows in flight at once (the register path is limited to U)
+// and staging costs no VALU per element.  Requires the whole [CP][PLANE] region to have been zeroed once
+// by the workgroup (halo columns and padded channels are never written here); rows outside the image are
+// zeroed explicitly.  The caller's __syncthreads() drains the DMAs (hipcc emits vmcnt(0) before the barrier).
+template <int C, int H, int W, int ROWS, int PW, int PLANE, int HALO, int NWAVES>
+__device__ __forceinline__ void stage_band_dma(const float *__restrict__ src, int img, int y0,
+                                               float *__restrict__ s_dst, int tid)
+{
+    using gptr_t = const __attribute__((address_space(1))) void *;
+    using lptr_t = __attribute__((address_space(3))) void *;
+    constexpr int NPASS = (W + 63) / 64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // A wave owns band rows r = wave, wave + NWAVES, ... and walks the channels inside: between two
+    // requests only a constant channel stride is added on both sides, so a request costs a few scalar
+    // instructions (decoding a flat (channel,row) index per request cost more issue time than the
+    // MFMAs the row feeds).
+#pragma unroll 1
+    for (int r = wave; r < ROWS; r += NWAVES) {
+        const int gy = y0 + r - HALO;
+        float *lrow = s_dst + r * PW + HALO;  // LDS address of column x = 0, channel 0
+        if (gy >= 0 && gy < H) {
+            const float *grow = src + ((size_t)img * C * H + gy) * W + lane;  // channel 0
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                if (lane + 64 * pass < W) {
+#pragma unroll 8
+                    for (int c = 0; c < C; ++c)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(grow + (size_t)c * H * W + 64 * pass),
+                                                         (lptr_t)(lrow + c * PLANE + 64 * pass), 4, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int x = lane + 64 * pass;
+                if (x < W)
+                    for (int c = 0; c < C; ++c) lrow[c * PLANE + x] = 0.f;
+            }
+        }
+    }
+}
+
+template <int WORDS, int NTHREADS>
+__device__ __forceinline__ void zero_lds(float *__restrict__ s, int tid)
+{
+    for (int i = tid; i < WORDS; i += NTHREADS) s[i] = 0.f;
 }
 
 }  // namespace ppo

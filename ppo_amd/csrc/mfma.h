@@ -15,4 +15,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ReLU as ONE VALU instruction (v_med3_f32 x, 0, +inf).  fmaxf(x, 0) costs two: hipcc first
+// canonicalises the operand with v_max x, x (IEEE quieting), which doubles the VALU work that sits
+// between MFMAs when ReLU is applied at operand-read time.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
 }  // namespace ppo
