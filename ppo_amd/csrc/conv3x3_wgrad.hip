@@ -186,48 +186,57 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
 }
 
 // dW[o][i][tap] = sum_wg partial[wg][o][tap*CINP + i]; db[o] = sum_wg partial[wg][o][9*CINP].
-// 64 outputs per workgroup, 4 threads per output each summing a quarter of the slabs, combined in LDS
-// in a fixed order.
+// A thread owns 4 consecutive j of one output channel (16-byte loads); 64 such quads per workgroup,
+// 4 threads per quad each summing a quarter of the slabs, combined in LDS in a fixed order.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ partial, int n_slabs,
                                                                    int cout, int cin, int cinp, int jp,
                                                                    float *__restrict__ dw, float *__restrict__ db,
                                                                    int accumulate)
 {
-    __shared__ float s[256];
-    const int nj = 9 * cinp + 1;
+    __shared__ float4 s[256];
+    const int q4 = jp / 4;  // quads per channel row
     const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
-    const bool live = idx < cout * nj;
-    const int co = live ? idx / nj : 0;
-    const int j = live ? idx % nj : 0;
+    const bool live = idx < cout * q4;
+    const int co = live ? idx / q4 : 0;
+    const int j0 = live ? (idx % q4) * 4 : 0;
     const size_t stride = (size_t)cout * jp;
-    const float *p = partial + (size_t)co * jp + j;
+    const float *p = partial + (size_t)co * jp + j0;
     const int per = (n_slabs + 3) / 4;
     const int lo = part * per;
     const int hi = lo + per < n_slabs ? lo + per : n_slabs;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (live) {
         int q = lo;
-        for (; q + 4 <= hi; q += 4) {
-            s0 += p[(size_t)(q + 0) * stride];
-            s1 += p[(size_t)(q + 1) * stride];
-            s2 += p[(size_t)(q + 2) * stride];
-            s3 += p[(size_t)(q + 3) * stride];
+        for (; q + 2 <= hi; q += 2) {
+            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
+            const float4 b = *reinterpret_cast<const float4 *>(p + (size_t)(q + 1) * stride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
         }
-        for (; q < hi; ++q) s0 += p[(size_t)q * stride];
+        for (; q < hi; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
     }
-    s[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    s[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
     __syncthreads();
     if (part == 0 && live) {
-        const float sum = (s[threadIdx.x] + s[threadIdx.x + 64]) + (s[threadIdx.x + 128] + s[threadIdx.x + 192]);
-        if (j == 9 * cinp) {
-            if (db) db[co] = accumulate ? db[co] + sum : sum;
-        } else {
-            const int tap = j / cinp;
-            const int ci = j % cinp;
-            if (ci < cin) {
-                float *d = dw + ((size_t)co * cin + ci) * 9 + tap;
-                *d = accumulate ? *d + sum : sum;
+        const float4 a = s[threadIdx.x], b = s[threadIdx.x + 64], c = s[threadIdx.x + 128], d = s[threadIdx.x + 192];
+        const float sum[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                              (a.w + b.w) + (c.w + d.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            if (j == 9 * cinp) {
+                if (db) db[co] = accumulate ? db[co] + sum[e] : sum[e];
+            } else if (j < 9 * cinp) {
+                const int tap = j / cinp;
+                const int ci = j % cinp;
+                if (ci < cin) {
+                    float *dst = dw + ((size_t)co * cin + ci) * 9 + tap;
+                    *dst = accumulate ? *dst + sum[e] : sum[e];
+                }
             }
         }
     }
@@ -262,7 +271,7 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWgradWaves * 64), C::LDS_BYTES, st, in, dy, workspace, n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
-    const int total = COUT * (9 * C::CINP + 1);
+    const int total = COUT * (C::JP / 4);  // one thread quad-group per 4 consecutive j
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, grid, COUT,
                        CIN, C::CINP, C::JP, dw, db, accumulate);
     return check_launch("conv3x3_wgrad_reduce_kernel");

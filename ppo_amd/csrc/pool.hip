@@ -1,26 +1,28 @@
 // 3x3 / stride 2 / pad 1 max pooling, NCHW float32 (reference: F.max_pool2d at
-// rl/impala.py:105) and its gradient.  HBM-bound elementwise-class kernels: one thread
-// per output element, coalesced along x.
+// rl/impala.py:105) and its gradient.  HBM-bound elementwise-class kernels.
 //
 // Forward optionally records which of the 9 window taps won (uint8), which is all the
 // backward pass needs: the gradient of an input element is the sum of the gradients of
 // the (at most four) windows that contain it and chose it.  Ties go to the first tap in
 // row-major window order, as in PyTorch's kernel (strict '>' scan).
+//
+// Indexing: blockIdx.y = (image, channel) plane, blockIdx.x * blockDim.x + threadIdx.x walks the
+// plane, so the only integer division per thread is by the row length.  The backward kernel
+// produces two adjacent input columns per thread (they share their candidate windows) and stores
+// them with one 8-byte access when the row length is even.
 #include "common.h"
 
 namespace ppo {
 namespace {
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                          uint8_t *__restrict__ argmax, int planes, int H, int W,
-                                                          int Ho, int Wo)
+                                                          uint8_t *__restrict__ argmax, int H, int W, int Ho, int Wo)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)planes * Ho * Wo;
-    if (idx >= total) return;
-    const int ox = idx % Wo;
-    const int oy = (idx / Wo) % Ho;
-    const int64_t pl = idx / ((int64_t)Wo * Ho);
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= Ho * Wo) return;
+    const int64_t pl = blockIdx.y;
+    const int oy = o / Wo;
+    const int ox = o - oy * Wo;
     const float *src = in + pl * H * W;
     float best = -INFINITY;
     int best_tap = 0;
@@ -41,40 +43,60 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restric
             }
         }
     }
-    out[idx] = best;
-    if (argmax) argmax[idx] = (uint8_t)best_tap;
+    out[pl * Ho * Wo + o] = best;
+    if (argmax) argmax[pl * Ho * Wo + o] = (uint8_t)best_tap;
 }
 
+// one thread -> input columns 2k, 2k+1 of one row
+template <bool PAIR_STORE>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ dout,
                                                           const uint8_t *__restrict__ argmax, float *__restrict__ din,
-                                                          int planes, int H, int W, int Ho, int Wo)
+                                                          int H, int W, int Ho, int Wo)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)planes * H * W;
-    if (idx >= total) return;
-    const int ix = idx % W;
-    const int iy = (idx / W) % H;
-    const int64_t pl = idx / ((int64_t)W * H);
+    const int Wh = (W + 1) / 2;  // column pairs per row
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= H * Wh) return;
+    const int64_t pl = blockIdx.y;
+    const int iy = t / Wh;
+    const int k = t - iy * Wh;
     const float *g = dout + pl * Ho * Wo;
     const uint8_t *a = argmax + pl * Ho * Wo;
-    // windows containing row iy: oy = iy/2 (tap row iy - 2oy + 1) and, for odd iy, oy = (iy+1)/2 (tap row 0)
-    float sum = 0.f;
-#pragma unroll
-    for (int sy = 0; sy < 2; ++sy) {
-        const int oy = (iy >> 1) + sy;
-        const int ky = iy - (2 * oy - 1);
-        if (sy == 1 && !(iy & 1)) continue;
-        if (oy >= Ho || ky < 0 || ky > 2) continue;
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            const int ox = (ix >> 1) + sx;
-            const int kx = ix - (2 * ox - 1);
-            if (sx == 1 && !(ix & 1)) continue;
-            if (ox >= Wo || kx < 0 || kx > 2) continue;
-            if (a[oy * Wo + ox] == ky * 3 + kx) sum += g[oy * Wo + ox];
+    // rows: oy0 = iy/2 holds tap row (iy even ? 1 : 2); for odd iy, oy0+1 holds tap row 0
+    const int oy0 = iy >> 1;
+    const int ky0 = (iy & 1) ? 2 : 1;
+    const bool has_oy1 = (iy & 1) && (oy0 + 1 < Ho);
+    // columns: ix0 = 2k is tap col 1 of ox = k; ix1 = 2k+1 is tap col 2 of ox = k and tap col 0 of ox = k+1
+    const bool has_ox1 = (k + 1 < Wo);
+    float s0 = 0.f, s1 = 0.f;
+    {
+        const int i00 = oy0 * Wo + k;
+        const int tap = a[i00];
+        const float gv = g[i00];
+        if (tap == ky0 * 3 + 1) s0 += gv;
+        if (tap == ky0 * 3 + 2) s1 += gv;
+        if (has_ox1) {
+            const int tap1 = a[i00 + 1];
+            if (tap1 == ky0 * 3 + 0) s1 += g[i00 + 1];
         }
     }
-    din[idx] = sum;
+    if (has_oy1) {
+        const int i10 = (oy0 + 1) * Wo + k;
+        const int tap = a[i10];
+        const float gv = g[i10];
+        if (tap == 1) s0 += gv;
+        if (tap == 2) s1 += gv;
+        if (has_ox1) {
+            const int tap1 = a[i10 + 1];
+            if (tap1 == 0) s1 += g[i10 + 1];
+        }
+    }
+    float *dst = din + pl * H * W + iy * W + 2 * k;
+    if (PAIR_STORE) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(s0, s1);
+    } else {
+        dst[0] = s0;
+        if (2 * k + 1 < W) dst[1] = s1;
+    }
 }
 
 }  // namespace
@@ -87,10 +109,10 @@ extern "C" int ppo_maxpool3x3s2_forward_f32(const float *in, float *out, uint8_t
     if (n < 0 || c <= 0 || h <= 0 || w <= 0) return fail(PPO_E_INVALID, "ppo_maxpool3x3s2_forward_f32: bad shape");
     if (n == 0) return PPO_OK;
     if (!in || !out) return fail(PPO_E_INVALID, "ppo_maxpool3x3s2_forward_f32: null pointer");
+    if ((int64_t)n * c > 65535 * 1024LL) return fail(PPO_E_INVALID, "ppo_maxpool3x3s2_forward_f32: too many planes");
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
-    const int64_t total = (int64_t)n * c * ho * wo;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in,
-                       out, argmax, n * c, h, w, ho, wo);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((ho * wo + 255) / 256, n * c), dim3(256), 0, as_stream(stream), in, out,
+                       argmax, h, w, ho, wo);
     return check_launch("maxpool_fwd_kernel");
 }
 
@@ -102,8 +124,11 @@ extern "C" int ppo_maxpool3x3s2_backward_f32(const float *dout, const uint8_t *a
     if (n == 0) return PPO_OK;
     if (!dout || !argmax || !din) return fail(PPO_E_INVALID, "ppo_maxpool3x3s2_backward_f32: null pointer");
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
-    const int64_t total = (int64_t)n * c * h * w;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       dout, argmax, din, n * c, h, w, ho, wo);
+    const int threads = h * ((w + 1) / 2);
+    const dim3 grid((threads + 255) / 256, n * c);
+    if (w % 2 == 0 && aligned(din, 8))
+        hipLaunchKernelGGL(maxpool_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), dout, argmax, din, h, w, ho, wo);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), dout, argmax, din, h, w, ho, wo);
     return check_launch("maxpool_bwd_kernel");
 }
