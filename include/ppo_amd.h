@@ -217,6 +217,29 @@ int ppo_moments_f64(const float *x, int64_t n, double *moments, void *workspace,
 int ppo_normalize_f32(const float *x, int64_t n, const double *moments, float eps, float *out, float *mean_std_out,
                       void *stream);
 
+/*
+ * Truncated-horizon (TVF) returns: the sampled weighted-n-step estimator of
+ * rl/returns_truncated.py:623-693 (_calculate_sampled_return_multi_fast, with _n_step_estimate :558-620 and
+ * _interpolate :142-174), as called by rl/tvf.py:250-262.
+ *   out[t,a,k] = mean_c( S_n[t,a] + interp(V[t+n,a,:], h_k-n) * D_n[t,a] ),  n = n_eff[k,c]
+ *   (rows with t >= N-n bootstrap from V[N,a,:] at horizon h_k-(N-t); horizons with k_zero[k] give 0)
+ * rewards [N,A] f32, dones [N,A] u8 (NumPy bool), value_samples [N+1,A,V] f32, out [N,A,K] f32.
+ * The caller resolves the horizon logic on the host (ppo_amd/returns_truncated.py) into device tables:
+ *   n_eff, nd_index [K,C] i32   n-step per sample (already clipped to h_k) and its slot in the prefix cache
+ *   nd_of_n [max_n+1] i32       cache slot of prefix length n (-1: not needed); ND slots
+ *   main_plan [K,C,3] i32 + main_w [K,C,2] f64      interpolation at horizon h_k-n: (mode, i0, i1), (w0, w1);
+ *   tail_plan [K,N+1,3] i32 + tail_w [K,N+1,2] f64   the same at horizon h_k-j, j = N-t;
+ *                               mode 0: zero, 1: V[i0], 2: f32(V[i0]*w0 + V[i1]*w1) evaluated in float64
+ * workspace: ppo_tvf_returns_workspace_bytes(N, A, ND) bytes.
+ * Algorithmic HBM traffic: 4*(N+1)*A*V read + 4*N*A*K written.
+ */
+size_t ppo_tvf_returns_workspace_bytes(int N, int A, int ND);
+int ppo_tvf_returns_f32(const float *rewards, const uint8_t *dones, const float *value_samples, int N, int A, int V,
+                        int K, int C, double gamma, const int32_t *n_eff, const int32_t *nd_index,
+                        const int32_t *nd_of_n, int max_n, int ND, const int32_t *main_plan, const double *main_w,
+                        const int32_t *tail_plan, const double *tail_w, const uint8_t *k_zero, void *workspace,
+                        size_t workspace_bytes, float *out, void *stream);
+
 /* ------------------------------------------------------------------------
  * Synthetic vectorised environment (HOST pointers; runs on host threads).
  * The benchmark workload of SURVEY.md §8(d): obs uint8 i.i.d. uniform, reward ~ N(0,1),
