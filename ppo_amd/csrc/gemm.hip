@@ -9,9 +9,11 @@
 // fa / fb: optional ReLU on load (the encoder keeps pre-activations and applies
 // ReLU when they are consumed); epi: optional [mask_src > 0] gate (ReLU backward).
 //
-// 64x64 output tile per 256-thread workgroup, 2x2 waves of 32x32, K staged through
-// LDS in 16-deep slabs.  Small grids are filled with split-K:
-// slices write [S][M][N] partials and gemm_finalize sums them in slice order
+// 64x64 output tile per 256-thread workgroup, 2x2 waves of 32x32, K staged through LDS in 32-deep
+// slabs.  Each operand slab is fetched with two 16-byte loads per thread along whichever axis is
+// contiguous in memory, one slab ahead (registers hold slab s+1 while the MFMAs run on slab s).
+// Operands that are not 16-byte friendly (heads: 13 rows) take a scalar path.  Small grids are
+// filled with split-K: slices write [S][M][N] partials and gemm_finalize sums them in slice order
 // (deterministic) and applies the epilogue.
 #include "common.h"
 #include "mfma.h"
@@ -19,11 +21,11 @@
 namespace ppo {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16;
-// Two LDS images per operand tile, chosen by which global axis is contiguous so that the
-// staging writes stay (nearly) conflict-free while the MFMA reads are conflict-free:
-//   k-major  [BK][PITCH_M]  (tile axis contiguous in memory)  PITCH_M = 16 mod 32
-//   m-major  [BM][PITCH_K]  (k contiguous in memory)          PITCH_K =  2 mod 32
+constexpr int BM = 64, BN = 64, BK = 32;
+// Two LDS images per operand tile, chosen by which global axis is contiguous:
+//   k-major  [BK][PITCH_M]  (tile axis contiguous in memory)  PITCH_M = 16 mod 32: conflict-free MFMA reads,
+//                                                             16-byte aligned rows for ds_write_b128
+//   m-major  [BM][PITCH_K]  (k contiguous in memory)          PITCH_K =  2 mod 32: conflict-free MFMA reads
 constexpr int PITCH_M = 80, PITCH_K = 34;
 constexpr int TILE_WORDS = BM * PITCH_K > BK * PITCH_M ? BM * PITCH_K : BK * PITCH_M;
 
@@ -38,12 +40,82 @@ struct GemmArgs {
     int relu_a, relu_b;
     int k_per_slice;
     int split;
+    int vec_a, vec_b;    // operand may be fetched with aligned float4 loads along its contiguous axis
 };
+
+// One operand slab (64 tile rows x 32 k) -> registers -> LDS.  `tfast`: the tile axis (m or n) is the
+// contiguous one, else k is.  rows = extent of the tile axis, t0/k0 origin, st/sk element strides.
+struct Slab {
+    float4 v[2];
+};
+
+__device__ __forceinline__ void slab_load(Slab &s, const float *__restrict__ P, int64_t st, int64_t sk, bool kfast,
+                                          bool vec, int t0, int rows, int k0, int kend, int tid)
+{
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = tid + e * 256;  // 512 float4 per slab
+        int tt, kk;
+        if (kfast) {
+            kk = (q & 7) * 4;  // 8 float4 along k
+            tt = q >> 3;       // 64 rows
+        } else {
+            tt = (q & 15) * 4;  // 16 float4 along the tile axis
+            kk = q >> 4;        // 32 k
+        }
+        const int gt = t0 + tt, gk = k0 + kk;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec) {
+            const bool in = kfast ? (gt < rows && gk + 3 < kend) : (gk < kend && gt + 3 < rows);
+            if (in) {
+                r = *reinterpret_cast<const float4 *>(P + gt * st + gk * sk);
+            } else {  // ragged edge: element-wise
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int g_t = kfast ? gt : gt + i, g_k = kfast ? gk + i : gk;
+                    if (g_t < rows && g_k < kend) t[i] = P[g_t * st + g_k * sk];
+                }
+                r = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        } else {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g_t = kfast ? gt : gt + i, g_k = kfast ? gk + i : gk;
+                if (g_t < rows && g_k < kend) t[i] = P[g_t * st + g_k * sk];
+            }
+            r = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        s.v[e] = r;
+    }
+}
+
+__device__ __forceinline__ void slab_store(const Slab &s, float *__restrict__ lds, bool kfast, bool relu, int tid)
+{
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = tid + e * 256;
+        float4 r = s.v[e];
+        if (relu) r = make_float4(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f));
+        if (kfast) {
+            const int kk = (q & 7) * 4, tt = q >> 3;
+            float *d = lds + tt * PITCH_K + kk;  // [tile row][k]
+            d[0] = r.x;
+            d[1] = r.y;
+            d[2] = r.z;
+            d[3] = r.w;
+        } else {
+            const int tt = (q & 15) * 4, kk = q >> 4;
+            *reinterpret_cast<float4 *>(lds + kk * PITCH_M + tt) = r;  // [k][tile row], 16-byte aligned
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
 {
-    __shared__ float s_a[TILE_WORDS];
-    __shared__ float s_b[TILE_WORDS];
+    __shared__ __align__(16) float s_a[TILE_WORDS];
+    __shared__ __align__(16) float s_b[TILE_WORDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -62,39 +134,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging maps: put consecutive threads along the unit-stride axis of each operand
     const bool a_kfast = p.a_sk == 1;
     const bool b_kfast = p.b_sk == 1;
-
+    Slab ra, rb;
+    if (kbeg < kend) {
+        slab_load(ra, p.A, p.a_sm, p.a_sk, a_kfast, p.vec_a, m0, p.M, kbeg, kend, tid);
+        slab_load(rb, p.B, p.b_sn, p.b_sk, b_kfast, p.vec_b, n0, p.N, kbeg, kend, tid);
+    }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();  // everyone is done reading the previous slab
+        slab_store(ra, s_a, a_kfast, p.relu_a, tid);
+        slab_store(rb, s_b, b_kfast, p.relu_b, tid);
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + e * 256;  // 0 .. 1023
-            {
-                const int kk = a_kfast ? (idx & 15) : (idx >> 6);
-                const int mm = a_kfast ? (idx >> 4) : (idx & 63);
-                const int gm = m0 + mm, gk = k0 + kk;
-                float v = 0.f;
-                if (gm < p.M && gk < kend) {
-                    v = p.A[gm * p.a_sm + gk * p.a_sk];
-                    if (p.relu_a) v = fmaxf(v, 0.f);
-                }
-                s_a[a_kfast ? mm * PITCH_K + kk : kk * PITCH_M + mm] = v;
-            }
-            {
-                const int kk = b_kfast ? (idx & 15) : (idx >> 6);
-                const int nn = b_kfast ? (idx >> 4) : (idx & 63);
-                const int gn = n0 + nn, gk = k0 + kk;
-                float v = 0.f;
-                if (gn < p.N && gk < kend) {
-                    v = p.B[gk * p.b_sk + gn * p.b_sn];
-                    if (p.relu_b) v = fmaxf(v, 0.f);
-                }
-                s_b[b_kfast ? nn * PITCH_K + kk : kk * PITCH_M + nn] = v;
-            }
+        if (k0 + BK < kend) {  // fetch the next slab while the MFMAs run
+            slab_load(ra, p.A, p.a_sm, p.a_sk, a_kfast, p.vec_a, m0, p.M, k0 + BK, kend, tid);
+            slab_load(rb, p.B, p.b_sn, p.b_sk, b_kfast, p.vec_b, n0, p.N, k0 + BK, kend, tid);
         }
-        __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             float a[2], b[2];
@@ -150,22 +205,31 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float *__restr
     C[m * ldc + n] = v;
 }
 
-// out[n] = sum_m f(X[m, n])   (bias gradients)
+// out[n] = sum_m X[m, n]   (bias gradients): 16 row partitions per column, combined in LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, int M, int N, int64_t ldx,
                                                      float *__restrict__ out, int accumulate)
 {
     __shared__ float s[256];
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;  // 4 row partitions
+    const int n = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int part = threadIdx.x >> 4;  // 16 row partitions
     float v = 0.f;
     if (n < N)
-        for (int m = part; m < M; m += 4) v += X[m * ldx + n];
+        for (int m = part; m < M; m += 16) v += X[m * ldx + n];
     s[threadIdx.x] = v;
     __syncthreads();
     if (part == 0 && n < N) {
-        const float t = (s[threadIdx.x] + s[threadIdx.x + 64]) + (s[threadIdx.x + 128] + s[threadIdx.x + 192]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += s[q * 16 + threadIdx.x];
         out[n] = accumulate ? out[n] + t : t;
     }
+}
+
+inline bool vec_ok(const float *P, int64_t s_tile, int64_t s_k)
+{
+    // float4 along the contiguous axis: the other stride and the base must keep 16-byte alignment
+    const int64_t other = s_k == 1 ? s_tile : s_k;
+    return (s_k == 1 || s_tile == 1) && other % 4 == 0 && aligned(P, 16);
 }
 
 }  // namespace
@@ -195,7 +259,7 @@ extern "C" int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu
     int kps = (K + split - 1) / split;
     kps = (kps + BK - 1) / BK * BK;
     GemmArgs p{A, B, split > 1 ? static_cast<float *>(workspace) : C, bias, mask, M, N, K, a_sm, a_sk, b_sk, b_sn,
-               ldc, relu_a, relu_b, kps, split};
+               ldc, relu_a, relu_b, kps, split, vec_ok(A, a_sm, a_sk) ? 1 : 0, vec_ok(B, b_sn, b_sk) ? 1 : 0};
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(gn, gm, split), dim3(256), 0, st, p);
     int rc = check_launch("gemm_f32_kernel");
     if (rc) return rc;
@@ -211,6 +275,6 @@ extern "C" int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *
 {
     using namespace ppo;
     if (M < 0 || N <= 0 || !X || !out) return fail(PPO_E_INVALID, "ppo_colsum_f32: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), X, M, N, ldx, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 15) / 16), dim3(256), 0, as_stream(stream), X, M, N, ldx, out, accumulate);
     return check_launch("colsum_kernel");
 }
