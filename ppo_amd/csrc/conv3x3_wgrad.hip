@@ -195,14 +195,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *
 {
     __shared__ float4 s[256];
     const int q4 = jp / 4;  // quads per channel row
-    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 16 + (threadIdx.x & 15);  // 16 output quads per workgroup
+    const int part = threadIdx.x >> 4;                      // 16 slab partitions per quad
     const bool live = idx < cout * q4;
     const int co = live ? idx / q4 : 0;
     const int j0 = live ? (idx % q4) * 4 : 0;
     const size_t stride = (size_t)cout * jp;
     const float *p = partial + (size_t)co * jp + j0;
-    const int per = (n_slabs + 3) / 4;
+    const int per = (n_slabs + 15) / 16;
     const int lo = part * per;
     const int hi = lo + per < n_slabs ? lo + per : n_slabs;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
@@ -222,9 +222,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *
     s[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
     __syncthreads();
     if (part == 0 && live) {
-        const float4 a = s[threadIdx.x], b = s[threadIdx.x + 64], c = s[threadIdx.x + 128], d = s[threadIdx.x + 192];
-        const float sum[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
-                              (a.w + b.w) + (c.w + d.w)};
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  // fixed order over the slab partitions
+            const float4 a = s[q * 16 + threadIdx.x];
+            sum[0] += a.x;
+            sum[1] += a.y;
+            sum[2] += a.z;
+            sum[3] += a.w;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = j0 + e;
@@ -272,7 +278,7 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
     const int total = COUT * (C::JP / 4);  // one thread quad-group per 4 consecutive j
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, workspace, grid, COUT,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, workspace, grid, COUT,
                        CIN, C::CINP, C::JP, dw, db, accumulate);
     return check_launch("conv3x3_wgrad_reduce_kernel");
 }
