@@ -78,6 +78,7 @@ class EnvConfig(_Group):  # rl/config.py:495-603
         ("timeout", int, 0, "episode step limit (0 = env default)"),
         ("synthetic_done_prob", float, 0.01, "synthetic env: per-step termination probability"),
         ("synthetic_threads", int, 8, "synthetic env: host threads generating observations"),
+        ("pipeline_parts", int, 2, "split the envs into this many groups so host stepping overlaps the GPU policy step"),
     )
 
 

@@ -4,7 +4,7 @@ env family constructed here is `synthetic`; for the real famili
 list of user-supplied `env_fns` (gym API) and returns the process-pool vector env.  Seeds follow the
 reference: env i gets base_seed + i*997 with i the GLOBAL env index (rl/envs.py:146)."""
 from .config import args
-from .vec_env import SyntheticVecEnv
+from .vec_env import SplitVecEnv, SyntheticVecEnv
 
 OBS_SHAPES = {"atari": (4, 84, 84), "procgen": (3, 64, 64), "synthetic": (4, 84, 84)}
 
@@ -28,5 +28,16 @@ def create_envs_classic(N=None, rank=0, world=1, env_fns=None):
         return HybridAsyncVectorEnv(env_fns, max_cpus=args.workers if args.workers > 0 else 8)
     shape, n_actions = get_env_spec()
     base_seed = args.seed if args.seed >= 0 else 0
-    return SyntheticVecEnv(N, obs_shape=shape, n_actions=n_actions, seed=base_seed, p_done=args.env.synthetic_done_prob,
-                           env_offset=rank * N, threads=args.env.synthetic_threads)
+
+
+    def make(n, offset):
+        return SyntheticVecEnv(n, obs_shape=shape, n_actions=n_actions, seed=base_seed,
+                               p_done=args.env.synthetic_done_prob, env_offset=offset,
+                               threads=args.env.synthetic_threads)
+
+    parts = int(getattr(args.env, "pipeline_parts", 2))
+    if parts > 1 and N % parts == 0 and N // parts >= 16:
+        # env streams are keyed by the GLOBAL env index, so the split changes nothing but the overlap
+        per = N // parts
+        return SplitVecEnv([make(per, rank * N + i * per) for i in range(parts)])
+    return make(N, rank * N)

@@ -26,7 +26,9 @@ def desync_envs(runner, min_duration: int, max_duration: int, verbose=True):
     for t in range(int(steps.max())):
         actions = np.random.randint(0, runner.n_actions, size=A).astype(np.int32)
         actions[t >= steps] = -1
-        if hasattr(runner.vec_env, "step_arrays"):
+        if hasattr(runner.vec_env, "step_all"):
+            runner.vec_env.step_all(actions)
+        elif hasattr(runner.vec_env, "step_arrays"):
             runner.obs, _, _ = runner.vec_env.step_arrays(actions)
         else:
             runner.obs, _, _, _ = runner.vec_env.step(actions)

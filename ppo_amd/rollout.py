@@ -81,6 +81,7 @@ class Runner:
         self._mean_std = torch.zeros(2, dtype=torch.float32, device=dev)
         self._grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sample_calls = 0
+        self._step_events = []
         self._stat_rows = None
         self.timers = {}
 
@@ -116,61 +117,103 @@ class Runner:
         self.step = 0
 
     # ------------------------------------------------------------------ rollout
-    def _policy_step(self, obs_dev, t):
-        """Forward + action sampling for one env step; writes row t of the rollout buffers."""
+    def _policy_step(self, t, lo=0, hi=None):
+        """Forward + action sampling for envs [lo, hi) at env step t; writes those columns of row t of the
+        rollout buffers.  The sampling counter is keyed by (rollout, t, env, action), so splitting the envs
+        into groups does not change which action any env takes."""
         net = self.net
-        acts = net.encode(obs_dev, train=False)
+        hi = self.A if hi is None else hi
+        acts = net.encode(self.all_obs[t, lo:hi], train=False)
         heads = net.heads(acts["h"], "i")
         A, nA = self.A, self.n_actions
         final = t >= self.N
         seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + self.rank
-        self._call("ppo_policy_act_f32", _p(heads), A, net.nh, nA, 1.0, None, seed & (2**64 - 1),
-                   self._sample_calls * A * nA, 0,
-                   None if final else _p(self.log_policy[t]), None if final else _p(self.actions[t]),
-                   None if final else _p(self.log_pac[t]), None if final else _p(self.raw_policy[t]),
-                   _p(self.value[t]), self.VH)
-        self._sample_calls += 1
+        counter = ((self._sample_calls + t) * A + lo) * nA
+        self._call("ppo_policy_act_f32", _p(heads), hi - lo, net.nh, nA, 1.0, None, seed & (2**64 - 1), counter, 0,
+                   None if final else _p(self.log_policy[t, lo:hi]), None if final else _p(self.actions[t, lo:hi]),
+                   None if final else _p(self.log_pac[t, lo:hi]), None if final else _p(self.raw_policy[t, lo:hi]),
+                   _p(self.value[t, lo:hi]), self.VH)
+
+    def _log_finished(self, finished, ep_len, ep_score):
+        if finished.any():
+            self.ep_count += int(finished.sum())
+            for s, l in zip(ep_score[finished][:8], ep_len[finished][:8]):
+                self.log.watch_full("ep_score", s, history_length=100)
+                self.log.watch_full("ep_length", l, history_length=100)
 
     def generate_rollout(self):
-        """Fill the rollout buffers with N steps from A envs (rl/rollout.py:702-969)."""
+        """Fill the rollout buffers with N steps from A envs (rl/rollout.py:702-969).
+
+        With a `SplitVecEnv` of array-stepping parts the step is software-pipelined: the GPU runs the policy
+        for one group of envs while the host steps the other group, so neither waits for the whole of the
+        other (the reference overlaps nothing: rl/rollout.py:792-816 is forward -> sync -> step)."""
         assert self.vec_env is not None, "Please attach vector environment first."
         N, A = self.N, self.A
         env = self.vec_env
-        fast = hasattr(env, "step_arrays")
-        rew_np, done_np = self._rewards_host.numpy(), self._dones_host.numpy()
-        act_np = self._actions_host.numpy()
-        obs_t = env.obs_t if fast else None
-        stream = torch.cuda.current_stream()
-        for t in range(N):
-            # H2D of this step's observations (pinned -> HBM), then policy + sampling on the GPU
-            src = obs_t if fast else torch.from_numpy(np.ascontiguousarray(self.obs))
-            self.all_obs[t].copy_(src, non_blocking=True)
-            self._policy_step(self.all_obs[t], t)
-            self._actions_host.copy_(self.actions[t], non_blocking=True)
-            stream.synchronize()  # the one device->host sync of the step: the envs need the actions
-            if fast:
-                self.obs, _, _ = env.step_arrays(act_np, rew_np[t], done_np[t])
-                ep_time, ep_len, ep_score = env.last_episode_stats
-                finished = done_np[t].astype(bool)
-            else:
-                self.obs, rew, dones, infos = env.step(act_np.copy())
-                rew_np[t] = rew
-                done_np[t] = dones
-                finished = np.asarray(dones, bool)
-                ep_len = np.asarray([i.get("ep_length", 0) for i in infos])
-                ep_score = np.asarray([i.get("ep_score", 0.0) for i in infos])
-            if finished.any():
-                self.ep_count += int(finished.sum())
-                for s, l in zip(ep_score[finished][:8], ep_len[finished][:8]):
-                    self.log.watch_full("ep_score", s, history_length=100)
-                    self.log.watch_full("ep_length", l, history_length=100)
-        # final state: value estimate of the state after the last action (rl/rollout.py:871-878)
-        src = obs_t if fast else torch.from_numpy(np.ascontiguousarray(self.obs))
-        self.all_obs[N].copy_(src, non_blocking=True)
-        self._policy_step(self.all_obs[N], N)
+        parts = getattr(env, "parts", [env])
+        if all(hasattr(p, "step_arrays") for p in parts):
+            self._rollout_pipelined(parts)
+        else:
+            self._rollout_generic(env)
         self.ext_rewards.copy_(self._rewards_host, non_blocking=True)
         self.terminals.view(torch.uint8).copy_(self._dones_host, non_blocking=True)
+        self._sample_calls += N + 1
         self.step += N * A * self.world
+
+    def _rollout_pipelined(self, parts):
+        N = self.N
+        rew_np, done_np = self._rewards_host.numpy(), self._dones_host.numpy()
+        act_np = self._actions_host.numpy()
+        bounds = np.cumsum([0] + [p.num_envs for p in parts]).tolist()
+        assert bounds[-1] == self.A
+        P = len(parts)
+        if len(self._step_events) < P:
+            self._step_events = [torch.cuda.Event() for _ in range(P)]
+        events = self._step_events
+
+        def enqueue(i, t):
+            # H2D of group i's observations (pinned -> HBM), policy + sampling, actions D2H; all async
+            lo, hi = bounds[i], bounds[i + 1]
+            self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
+            self._policy_step(t, lo, hi)
+            if t < N:
+                self._actions_host[lo:hi].copy_(self.actions[t, lo:hi], non_blocking=True)
+                events[i].record()
+
+        def step_envs(i, t):
+            # the one host wait of group i's step: its actions have landed; then step it on host cores
+            lo, hi = bounds[i], bounds[i + 1]
+            events[i].synchronize()
+            parts[i].step_arrays(act_np[lo:hi], rew_np[t, lo:hi], done_np[t, lo:hi])
+            _, ep_len, ep_score = parts[i].last_episode_stats
+            self._log_finished(done_np[t, lo:hi].astype(bool), ep_len, ep_score)
+
+        for t in range(N + 1):
+            for i in range(P):
+                enqueue(i, t)  # needs obs(i, t): group i was stepped for t-1 below
+                j, tj = (i + 1) % P, (t if i + 1 == P else t - 1)
+                if 0 <= tj < N:
+                    step_envs(j, tj)  # overlaps the GPU work just queued for group i
+        self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
+
+    def _rollout_generic(self, env):
+        """gym-API vector env (`step(actions) -> obs, rew, done, infos`), one group."""
+        N = self.N
+        rew_np, done_np = self._rewards_host.numpy(), self._dones_host.numpy()
+        act_np = self._actions_host.numpy()
+        stream = torch.cuda.current_stream()
+        for t in range(N + 1):
+            self.all_obs[t].copy_(torch.from_numpy(np.ascontiguousarray(self.obs)), non_blocking=True)
+            self._policy_step(t)
+            if t == N:
+                break  # final state: only its value estimate is needed (rl/rollout.py:871-878)
+            self._actions_host.copy_(self.actions[t], non_blocking=True)
+            stream.synchronize()  # the one device->host sync of the step: the envs need the actions
+            self.obs, rew, dones, infos = env.step(act_np.copy())
+            rew_np[t] = rew
+            done_np[t] = dones
+            self._log_finished(np.asarray(dones, bool), np.asarray([i.get("ep_length", 0) for i in infos]),
+                               np.asarray([i.get("ep_score", 0.0) for i in infos]))
 
     # ------------------------------------------------------------------ returns
     def calculate_returns(self):
@@ -263,7 +306,7 @@ class Runner:
         torch.save(data, filename)
 
     def load_checkpoint(self, checkpoint_path):
-        cp = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        cp = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         self.model.load_state_dict(cp["model_state_dict"])
         if "policy_optimizer_state_dict" in cp:
             self.net.load_optimizer_state_dict(cp["policy_optimizer_state_dict"])

@@ -86,6 +86,33 @@ def test_train_normalises_advantages_and_updates_policy(runner):
     assert torch.equal(r.net.params["advantage_head.weight"], before[r.net._offsets["advantage_head.weight"][0]:][:6 * 256].view(6, 256))
 
 
+def test_pipelined_rollout_equals_unsplit_rollout(runner):
+    """Splitting the envs into two groups (host stepping of one overlaps the GPU policy step of the other)
+    must not change a single byte of the rollout: env streams and the sampling counter are keyed by the
+    global env index.  Runs on the module's model; A=32 so that each group has 16 envs."""
+    from ppo_amd.vec_env import SplitVecEnv, SyntheticVecEnv
+    old = (args.agents, args.n_steps)
+    args.agents, args.n_steps = 32, 8
+    try:
+        outs = []
+        for parts in (1, 2):
+            r = rollout.Runner(runner.model, logger.Logger(quiet=True))
+            per = 32 // parts
+            envs_ = [SyntheticVecEnv(per, seed=3, p_done=0.05, env_offset=i * per, threads=2) for i in range(parts)]
+            r.vec_env = envs_[0] if parts == 1 else SplitVecEnv(envs_)
+            r.reset()
+            r.generate_rollout()
+            r.generate_rollout()  # second rollout: the sampling counter advanced identically
+            torch.cuda.synchronize()
+            outs.append([x.cpu().clone() for x in (r.all_obs, r.actions, r.log_policy, r.value, r.ext_rewards,
+                                                   r.terminals, r.log_pac)] + [torch.from_numpy(np.array(r.obs))])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert outs[0][5].any() and len(torch.unique(outs[0][1])) > 1
+    finally:
+        args.agents, args.n_steps = old
+
+
 def test_second_iteration_runs_and_checkpoint_round_trips(runner, tmp_path):
     r = runner
     r.generate_rollout()
