@@ -73,7 +73,9 @@ class EnvConfig(_Group):  # rl/config.py:495-603
         ("embed_time", bool, True, "append a time channel"),
         ("embed_action", bool, True, "embed last action"),
         ("reward_normalization", str, "rms", "[off|rms]"),
-        ("reward_clip", float, 10.0, "clip normalised rewards"),
+        ("reward_normalization_clipping", float, 10.0, "clip rewards after normalisation, negative to disable (:509)"),
+        ("max_repeated_actions", int, 100, "penalise repeating one action more than this many times (:513)"),
+        ("repeated_action_penalty", float, 0.0, "the penalty (:514)"),
         ("warmup_period", int, 250, "random warm-up steps to desynchronise envs"),
         ("timeout", int, 0, "episode step limit (0 = env default)"),
         ("synthetic_done_prob", float, 0.01, "synthetic env: per-step termination probability"),
@@ -138,6 +140,8 @@ class Config:
         self.threads = 2               # :723
         self.precision = "medium"      # :764
         self.use_intrinsic_rewards = False
+        self.sync_envs = False
+        self.override_reward_normalization_gamma = None  # :780
         self.log_folder = None
         self._ignored = []
 
@@ -145,6 +149,12 @@ class Config:
     @property
     def batch_size(self):
         return self.n_steps * self.agents
+
+    @property
+    def reward_normalization_gamma(self):  # rl/config.py:875-880
+        if self.override_reward_normalization_gamma is not None:
+            return self.override_reward_normalization_gamma
+        return self.tvf.gamma if self.tvf.enabled else self.gamma
 
     @property
     def tvf_return_n_step(self):
@@ -185,6 +195,8 @@ class Config:
         a("--threads", type=int, default=self.threads)
         a("--precision", type=str, default=self.precision, help="[low|medium|high]; all run exact fp32 here")
         a("--use_intrinsic_rewards", type=str2bool, nargs="?", const=True, default=False)
+        a("--sync_envs", type=str2bool, nargs="?", const=True, default=False)
+        a("--override_reward_normalization_gamma", type=float, default=None)
         for g in self._groups:
             g.add(p)
         return p

@@ -1,0 +1,147 @@
+"""Vector-env wrappers that sit either side of the rollout every step — host mirror of the reference's
+rl/wrappers.py `VecNormalizeRewardWrapper` (:795-919) and `VecRepeatedActionPenalty` (:758-793).
+
+No gym in this image: a wrapper here is a plain object that forwards unknown attributes to the env it
+wraps (`num_envs`, `seed`, `save_state`...), which is all the trainer relies on.
+"""
+import math
+
+import numpy as np
+
+from .running_stats import RunningMeanStd
+
+
+class VecWrapper:
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):  # only called for attributes not found on the wrapper itself
+        if name == "env":
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def step(self, actions):
+        return self.env.step(actions)
+
+    def close(self):
+        return self.env.close()
+
+
+def get_wrapper(env, wrapper_type):
+    """Walk the `.env` chain for the first wrapper of the given type (rl/wrappers.py `get_wrapper`)."""
+    while env is not None:
+        if isinstance(env, wrapper_type):
+            return env
+        env = env.__dict__.get("env")
+    return None
+
+
+class VecRepeatedActionPenalty(VecWrapper):
+    """Subtract `penalty` from the reward of any env that has repeated one action more than
+    `max_repeated_actions` times in a row; action -1 (env skipped) neither counts nor resets."""
+
+    def __init__(self, env, max_repeated_actions: int, penalty: float = 1):
+        super().__init__(env)
+        self.max_repeated_actions = max_repeated_actions
+        self.penalty = penalty
+        self.prev_actions = np.zeros([env.num_envs], dtype=np.int32)
+        self.duplicate_counter = np.zeros([env.num_envs], dtype=np.int32)
+
+    def reset(self, **kwargs):
+        self.prev_actions[:] = 0
+        self.duplicate_counter[:] = 0
+        return self.env.reset()
+
+    def step(self, actions):
+        obs, rewards, dones, infos = self.env.step(actions)
+        actions = np.asarray(actions)
+        repeated = (actions == self.prev_actions) & (actions >= 0)
+        self.duplicate_counter = (self.duplicate_counter + repeated) * repeated
+        over = self.duplicate_counter > self.max_repeated_actions
+        infos[0]["max_repeats"] = np.max(self.duplicate_counter)
+        infos[0]["mean_repeats"] = np.mean(self.duplicate_counter)
+        for i in np.flatnonzero(over):
+            infos[i]["repeated_action"] = actions[i]
+        self.prev_actions[:] = actions
+        return obs, rewards - (over * self.penalty), dones, infos
+
+
+class VecNormalizeRewardWrapper(VecWrapper):
+    """Scale rewards so discounted returns have roughly unit variance, then clip:
+        R <- r + gamma * R * (1 - done);  running var over every R seen;  r' = clip(r / sqrt(var + 1e-2), +-clip) * scale
+
+    `moments_sync`, if given, maps np.array([sum, sum_sq, n]) of this step's R to the same moments summed
+    over all data-parallel ranks, so every rank keeps the normaliser a single process with all envs would."""
+
+    def __init__(self, env, initial_state=None, gamma: float = 1.0, clip: float = 10.0, scale: float = 1.0,
+                 returns_transform=lambda x: x, mode: str = "rms", ed_type=None, ed_bias: float = 1.0,
+                 ema_horizon: float = 5e6, moments_sync=None):
+        super().__init__(env)
+        if ed_type is not None:
+            raise NotImplementedError("episodic discounting normalisation is outside the PPO hot path")
+        if mode not in ("rms", "ema", "custom"):
+            raise ValueError(f"Invalid mode {mode}")
+        self.clip = clip
+        self.epsilon = 1e-2
+        self.current_returns = np.zeros([env.num_envs], dtype=np.float32)
+        self.ret_rms = RunningMeanStd(shape=())
+        self.gamma = gamma
+        self.scale = scale
+        self.mode = mode
+        self.returns_transform = returns_transform
+        self.ret_var = 0.0
+        self.ema_horizon = ema_horizon
+        self.moments_sync = moments_sync
+        if initial_state is not None:
+            self.ret_rms.restore_state(initial_state)
+
+    def reset(self):
+        self.current_returns *= 0
+        return self.env.reset()
+
+    def _update(self, x):
+        if self.moments_sync is None:
+            self.ret_rms.update(x)
+            return
+        x64 = np.asarray(x, np.float64)
+        s, ss, n = self.moments_sync(np.array([x64.sum(), np.square(x64).sum(), float(x64.shape[0])]))
+        mean = s / n
+        self.ret_rms.update_from_moments(mean, max(ss / n - mean * mean, 0.0), n)
+
+    def step(self, actions):
+        obs, rewards, dones, infos = self.env.step(actions)
+        self.current_returns = rewards + self.gamma * self.current_returns * (1 - dones)
+        self._update(self.returns_transform(self.current_returns))
+        if self.mode == "ema":
+            alpha = 1 - (len(dones) / min(self.ret_rms.count, self.ema_horizon))
+            self.ret_var = alpha * self.ret_var + (1 - alpha) * np.var(self.current_returns)
+        scaled = rewards / self.std
+        if self.clip is not None and self.clip >= 0:
+            clipped = np.clip(scaled, -self.clip, +self.clip)
+            clips = np.sum(clipped != scaled)
+            if clips > 0:
+                infos[0]["reward_clips"] = clips
+            scaled = clipped
+        scaled = scaled * self.scale
+        return obs, scaled, dones, infos
+
+    @property
+    def mean(self):
+        return self.ret_rms.mean
+
+    @property
+    def std(self):
+        return math.sqrt((self.ret_rms.var if self.mode == "rms" else self.ret_var) + self.epsilon)
+
+    def save_state(self, buffer):
+        buffer["ret_rms"] = self.ret_rms.save_state()
+        buffer["ret_var"] = self.ret_var
+        buffer["current_returns"] = self.current_returns
+
+    def restore_state(self, buffer):
+        self.ret_var = buffer["ret_var"]
+        self.ret_rms.restore_state(buffer["ret_rms"])
+        self.current_returns = buffer["current_returns"]

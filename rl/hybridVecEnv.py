@@ -1,2 +1,2 @@
-from ppo_amd.vec_env import *  # noqa: F401,F403
-from ppo_amd.vec_env import SyntheticVecEnv  # noqa: F401
+from ppo_amd.hybrid_vec_env import HybridAsyncVectorEnv  # noqa: F401
+from ppo_amd.vec_env import SplitVecEnv, SyntheticVecEnv  # noqa: F401
