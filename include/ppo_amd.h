@@ -186,6 +186,65 @@ int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_va
  * returns at row index[b] of the whole-batch arrays (the minibatch permutation), so those need no gather. */
 
 /*
+ * Elementwise tanh and its backward dx = dy * (1 - y^2), y = tanh(x)  (torch.tanh at rl/models.py:166,
+ * 456-457: the MLP encoder and the `tanh` encoder activation of the mujoco configs).
+ */
+int ppo_tanh_forward_f32(const float *x, float *y, size_t n, void *stream);
+int ppo_tanh_backward_f32(const float *dy, const float *y, float *dx, size_t n, void *stream);
+
+/*
+ * Value-phase loss of the dual architecture (Runner.train_value_minibatch, rl/rollout.py:1513-1567):
+ *   loss_b = sum_{i<n_value_heads} vf_coef (V_i - R_i)^2                         (rl/rollout.py:1596-1608; returns nullable)
+ *          + tvf_coef * 0.5 * sqrt(K) * mean_k w_k (T_k - P_k)^2                 (rl/tvf.py:49-73; tvf_returns nullable)
+ * V_i = heads[b, value_col + i]; P_k = heads[b, tvf_col + k*tvf_stride] (the `ext` column of TVF head k);
+ * returns [*,n_value_heads], tvf_returns [*,n_tvf], tvf_weights [n_tvf] (nullable = 1).  dheads [B,ldo] gets
+ * grad_scale * d loss_b / d heads over the WHOLE row (zeros elsewhere).  stats (nullable) [B,4]: value
+ * loss, TVF loss, total, 0.  index as in ppo_ppo_loss_f32.
+ */
+int ppo_value_loss_f32(const float *heads, int B, int ldo, int value_col, int n_value_heads, const float *returns,
+                       float vf_coef, int tvf_col, int n_tvf, int tvf_stride, const float *tvf_returns,
+                       const float *tvf_weights, float tvf_coef, float grad_scale, float *dheads, float *stats,
+                       const int32_t *index, void *stream);
+
+/*
+ * Distillation-phase loss (Runner.train_distil_minibatch, rl/rollout.py:1331-1449; value_loss "mse"):
+ *   loss_b = 0.5 w_k (T_k - P_k)^2  [* sqrt(n_pred) mean_k when vector_targets]  + beta * policy term
+ * P_k = heads[b, pred_col + k*pred_stride]; targets [*,n_pred]; weights [n_pred] nullable.
+ * Policy term: log_std == NULL -> KL(pi_new || pi_old) with old_policy = old log-probabilities [*,n_actions]
+ * (distil loss "kl_policy", :1414-1415); log_std != NULL (gaussian policies, :1401-1409) ->
+ * 2 * 0.5 mean_a (mu_old - mu)^2 / (1e-5 + 2 exp(log_std_a)^2) with old_policy = old means (the reference
+ * adds this term twice, :1409 and :1419; its scale is kept).
+ * stats (nullable) [B,4]: value loss, policy loss, total, mean_k (w_k (P_k - T_k))^2.
+ */
+int ppo_distil_loss_f32(const float *heads, int B, int ldo, int n_actions, int pred_col, int n_pred, int pred_stride,
+                        int vector_targets, const float *targets, const float *weights, const float *old_policy,
+                        const float *log_std, float beta, float grad_scale, float *dheads, float *stats,
+                        const int32_t *index, void *stream);
+
+/*
+ * Gaussian policy (action_dist "gaussian", rl/rollout.py:643-648): mu = heads[b, :n_actions],
+ * action = mu + exp(log_std) * n with n ~ N(0,1) from `normal` [B,n_actions] if given, else Box-Muller on the
+ * counter-based uniform stream keyed by (seed, offset + b*n_actions + a); deterministic != 0 -> action = mu.
+ * Outputs (nullable): actions, log_pac (= Normal(mu, sigma).log_prob(action) per dimension, :1877-1880),
+ * raw_policy (mu), all [B,n_actions]; values [B,n_value_heads].
+ */
+int ppo_gaussian_act_f32(const float *heads, int B, int ldo, int n_actions, const float *log_std, const float *normal,
+                         uint64_t seed, uint64_t offset, int deterministic, float *actions, float *log_pac,
+                         float *raw_policy, float *values, int n_value_heads, void *stream);
+
+/*
+ * PPO minibatch loss for gaussian policies (rl/rollout.py:1693-1704, 1744-1753):
+ *   gain_b = mean_a min(rho_a A, clip(rho_a) A) - sum_heads vf_coef (V - R)^2,  rho_a = exp(logN(a_a; mu_a, sigma_a) - old_log_pac_a)
+ * actions, old_log_pac [*,n_actions] f32.  dheads as in ppo_ppo_loss_f32; dlog_std_rows (nullable) [B,n_actions]
+ * receives each sample's d loss / d log_std (sum the rows with ppo_colsum_f32).  stats (nullable) [B,8] in
+ * ppo_ppo_loss_f32's column order (entropy / KL(new||old) columns are 0, as in the reference).
+ */
+int ppo_gaussian_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_value_heads, const float *actions,
+                          const float *old_log_pac, const float *advantages, const float *returns,
+                          const float *log_std, float eps_clip, float vf_coef, float grad_scale, float *dheads,
+                          float *dlog_std_rows, float *stats, const int32_t *index, void *stream);
+
+/*
  * One optimiser step on a flat parameter buffer: global-norm clip (clip_grad_norm_,
  * rl/rollout.py:1309-1310; max_grad_norm <= 0 disables) then torch.optim.Adam's update
  * (rl/rollout.py:126-141).  grads are divided by grad_div first (world size after an

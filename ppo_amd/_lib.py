@@ -56,6 +56,12 @@ SIGNATURES = {
     "ppo_synth_env_reset": (_i, [_vp, _vp]),
     "ppo_synth_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "ppo_tanh_backward_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "ppo_value_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "ppo_distil_loss_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "ppo_gaussian_act_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ppo_gaussian_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
 }

@@ -43,9 +43,19 @@ class _Group:
 
 
 class OptimizerConfig(_Group):  # rl/config.py:249-311
+    EPOCH_DEFAULTS = {"policy_opt": 2, "value_opt": 1, "distil_opt": 2}  # :261-267
+
+    def __init__(self, prefix):
+        super().__init__(prefix)
+        self.epochs = self.EPOCH_DEFAULTS.get(prefix, 0)
+
+    def add(self, parser):
+        super().add(parser)
+        parser.set_defaults(**{f"{self._prefix}_epochs": self.EPOCH_DEFAULTS.get(self._prefix, 0)})
+
     FIELDS = (
         ("optimizer", str, "adam", "[adam]"),
-        ("epochs", int, 2, "training epochs per batch"),
+        ("epochs", int, 2, "training epochs per batch (default: policy 2, value 1, distil 2)"),
         ("mini_batch_size", int, 256, "examples per optimisation step (global, across ranks)"),
         ("lr", float, 2.5e-4, "learning rate"),
         ("lr_anneal", bool, False, "anneal learning rate linearly to 0"),
@@ -84,6 +94,22 @@ class EnvConfig(_Group):  # rl/config.py:495-603
     )
 
 
+class DistilConfig(_Group):  # rl/config.py:329-354
+    FIELDS = (
+        ("order", str, "after_policy", "[after_policy|before_policy]"),
+        ("beta", float, 1.0, "weight of the policy constraint"),
+        ("target", str, "value", "[value]  (return / advantage targets are not built)"),
+        ("batch_size", int, -1, "distil batch size, negative = the rollout"),
+        ("period", int, 1, "distil every this many batches"),
+        ("loss", str, "kl_policy", "[kl_policy]"),
+        ("max_heads", int, -1, "max TVF heads to distil, -1 = all"),
+        ("force_ext", bool, False, "distil the ext value head even when TVF is on"),
+        ("value_loss", str, "mse", "[mse]"),
+        ("delay", float, 0, "millions of steps before distillation starts"),
+        ("use_policy_opt", bool, False, "share the policy optimiser's moments"),
+    )
+
+
 class TVFConfig(_Group):  # rl/config.py:209-246
     FIELDS = (
         ("enabled", bool, False, "truncated value functions"),
@@ -96,6 +122,10 @@ class TVFConfig(_Group):  # rl/config.py:209-246
         ("return_distribution", str, "exponential", "[fixed|exponential|uniform|hyperbolic|quadratic]"),
         ("return_samples", int, 8, "n-step samples per horizon"),
         ("return_use_log_interpolation", bool, False, "interpolate in log-horizon space"),
+        ("include_ext", bool, False, "also train the ext value head in the value phase"),
+        ("trimming", str, "off", "[off]  (horizon trimming is not built)"),
+        ("head_weighting", str, "off", "[off]"),
+        ("horizon_dropout", float, 0.0, "must be 0 (not built)"),
     )
 
 
@@ -103,10 +133,12 @@ class Config:
     def __init__(self):
         self.policy_opt = OptimizerConfig("policy_opt")
         self.value_opt = OptimizerConfig("value_opt")
+        self.distil_opt = OptimizerConfig("distil_opt")
+        self.distil = DistilConfig("distil")
         self.model = ModelConfig("model")
         self.env = EnvConfig("env")
         self.tvf = TVFConfig("tvf")
-        self._groups = (self.policy_opt, self.value_opt, self.model, self.env, self.tvf)
+        self._groups = (self.policy_opt, self.value_opt, self.distil_opt, self.distil, self.model, self.env, self.tvf)
         # top-level defaults (rl/config.py line numbers)
         self.agents = 256              # :791
         self.n_steps = 256             # :790

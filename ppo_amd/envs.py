@@ -58,6 +58,7 @@ def create_envs_classic(N=None, rank=0, world=1, env_fns=None, monitor_video=Fal
         while len(env_fns) % workers:
             workers -= 1
         vec_env = HybridAsyncVectorEnv(env_fns, copy=False, max_cpus=workers)
+        vec_env.pin()  # async H2D straight out of the shared observation block
         if args.env.reward_normalization == "rms":
             vec_env = wrappers.VecNormalizeRewardWrapper(
                 vec_env, gamma=args.reward_normalization_gamma, mode="rms", clip=args.env.reward_normalization_clipping,

@@ -1,10 +1,11 @@
-"""Policy/value network on hand-written HIP kernels — host mirror of the reference's
-rl/models.py (TVFModel :511-856, DualHeadNet :304-508, ImpalaCNN :54-99) and rl/impala.py.
+"""Policy/value networks on hand-written HIP kernels — host mirror of the reference's
+rl/models.py (TVFModel :511-856, DualHeadNet :304-508, ImpalaCNN :54-99, StandardMLP :148-169) and
+rl/impala.py.
 
 The network's arithmetic runs entirely in libppo_amd.so (f32-MFMA convolutions and GEMMs,
-fused load transforms, fused PPO loss, fused Adam); this module owns the memory plan and the
-call order.  Parameters live in ONE flat float32 device buffer (so the optimiser step and the
-RCCL gradient all-reduce are single launches) and are exposed under the reference's
+fused load transforms, fused losses, fused Adam); this module owns the memory plan and the
+call order.  Parameters of one net live in ONE flat float32 device buffer (so the optimiser step
+and the RCCL gradient all-reduce are single launches) and are exposed under the reference's
 ``state_dict`` names, so reference checkpoints load unchanged.
 
 torch is used for device memory, views and (on the CPU, at construction only) the reference's
@@ -21,6 +22,7 @@ from . import _lib
 
 IN_NONE, IN_RELU, IN_U8 = _lib.PPO_IN_NONE, _lib.PPO_IN_RELU, _lib.PPO_IN_U8
 _ALIGN = 4  # floats: every parameter starts on a 16-byte boundary
+HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
 def _p(t):
@@ -60,6 +62,7 @@ def _custom_linear(fin, fout, scale=1.0, bias=True):
 
 class ImpalaSpec:
     """Static geometry of the IMPALA encoder (rl/models.py:54-99, rl/impala.py:85-123)."""
+    kind = "impala"
 
     def __init__(self, input_dims, channels=(16, 32, 32), n_block=2, hidden_units=256):
         c, h, w = input_dims
@@ -76,12 +79,28 @@ class ImpalaSpec:
         self.flat = c * h * w
 
 
-def init_impala_parameters(spec: ImpalaSpec, n_actions: int, vh: int, head_scale: float, head_bias: bool):
-    """Initial parameters of DualHeadNet(encoder='impala') as CPU tensors, drawn from torch's global
-    CPU generator in the reference's construction order (rl/models.py:348-368, :73-84; rl/impala.py:60-62,
-    96-100), so that the same ``torch.manual_seed`` reproduces the reference's initial weights exactly.
-    Keys are the reference's names relative to ``policy_net``."""
+class MLPSpec:
+    """StandardMLP (rl/models.py:148-169): fc1 -> tanh -> fc2 on a flat float observation."""
+    kind = "mlp"
+
+    def __init__(self, input_dims, hidden_units=64):
+        if len(input_dims) != 1:
+            raise ValueError(f"the mlp encoder takes flat observations, got input_dims={input_dims}")
+        self.input_dims = tuple(input_dims)
+        self.in_features = int(input_dims[0])
+        self.hidden_units = hidden_units
+
+
+def init_encoder_parameters(spec):
+    """Encoder parameters as CPU tensors, drawn from torch's global CPU generator in the reference's
+    construction order (impala: rl/models.py:73-84, rl/impala.py:60-62, 96-100; mlp: rl/models.py:157-161)."""
     init = OrderedDict()
+    if spec.kind == "mlp":
+        w, b = _custom_linear(spec.in_features, spec.hidden_units, scale=torch.nn.init.calculate_gain("tanh"))
+        init["encoder.fc1.weight"], init["encoder.fc1.bias"] = w, b
+        w, b = _custom_linear(spec.hidden_units, spec.hidden_units, scale=1.414)
+        init["encoder.fc2.weight"], init["encoder.fc2.bias"] = w, b
+        return init
     s_stack = 1 / math.sqrt(len(spec.channels))  # rl/models.py:75
     for si, (cin, cout, *_r) in enumerate(spec.stacks):
         w, b = _normed_conv(cin, cout)  # firstconv: scale 1 (rl/impala.py:96)
@@ -94,28 +113,63 @@ def init_impala_parameters(spec: ImpalaSpec, n_actions: int, vh: int, head_scale
                 init[f"encoder.stacks.{si}.blocks.{bi}.{cname}.bias"] = b
     w, b = _normed_linear(spec.flat, spec.hidden_units, scale=1.414)  # rl/models.py:84
     init["encoder.dense.weight"], init["encoder.dense.bias"] = w, b
-    for name, rows in (("policy_head", n_actions), ("value_head", vh), ("advantage_head", n_actions)):
+    return init
+
+
+def init_parameters(spec, n_actions: int, vh: int, head_scale: float, head_bias: bool, n_tvf: int = 0):
+    """Initial parameters of DualHeadNet as CPU tensors in the reference's construction order
+    (rl/models.py:348-384: encoder, policy / value / advantage heads, log_std, then the TVF head), so
+    that the same ``torch.manual_seed`` reproduces the reference's initial weights exactly.
+    Keys are the reference's names relative to ``policy_net``."""
+    init = init_encoder_parameters(spec)
+    heads = [("policy_head", n_actions), ("value_head", vh), ("advantage_head", n_actions)]
+    if n_tvf:
+        heads.append(("tvf_head", n_tvf * vh))
+    for name, rows in heads:
         w, b = _custom_linear(spec.hidden_units, rows, scale=head_scale, bias=head_bias)
         init[f"{name}.weight"] = w
         if head_bias:
             init[f"{name}.bias"] = b
-    init["log_std"] = torch.zeros(n_actions)  # rl/models.py:368
+    init["log_std"] = torch.zeros(n_actions)  # rl/models.py:368 (no random draw, so its position is free)
     return init
 
 
-class DualHeadNet:
-    """One encoder + policy / value / advantage heads (reference: rl/models.py:304-508), HIP-backed.
+def init_impala_parameters(spec: ImpalaSpec, n_actions: int, vh: int, head_scale: float, head_bias: bool):
+    return init_parameters(spec, n_actions, vh, head_scale, head_bias)
 
-    Only the IMPALA encoder is built on this path (``encoder='impala'``).
+
+class AdamState:
+    """Adam moments + step count over a net's flat parameter buffer."""
+
+    def __init__(self):
+        self.exp_avg = self.exp_avg_sq = None
+        self.step = 0
+
+    def ensure(self, flat):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+
+
+class DualHeadNet:
+    """One encoder + policy / value / advantage (/ TVF) heads (reference: rl/models.py:304-508), HIP-backed.
+
+    Encoders: ``impala`` (3x3 conv stacks, uint8 or float images) and ``mlp`` (flat float observations);
+    encoder activation ``relu`` (fused into the head GEMM's operand load) or ``tanh``.  All heads are ONE
+    [nh, hidden] matrix so a forward is one GEMM: columns [policy nA | value VH | advantage nA | tvf K*VH].
     """
 
     def __init__(self, encoder: str, input_dims, n_actions: int, hidden_units: int = 256,
-                 activation_fn: str = "relu", head_scale: float = 1.0, value_head_names=("ext",),
+                 activation_fn: str = "relu", tvf_fixed_head_horizons=None, tvf_feature_sparsity: float = 0.0,
+                 tvf_feature_window: int = -1, head_scale: float = 1.0, value_head_names=("ext",),
                  head_bias: bool = False, device="cuda", **encoder_args):
-        if encoder.lower() != "impala":
-            raise NotImplementedError(f"encoder '{encoder}' has no HIP path yet (impala only)")
-        if activation_fn != "relu":
-            raise NotImplementedError("the impala path uses relu after the encoder (rl/train.py:67)")
+        encoder = encoder.lower()
+        if encoder not in ("impala", "mlp"):
+            raise NotImplementedError(f"encoder '{encoder}' has no HIP path (impala | mlp)")
+        if activation_fn not in ("relu", "tanh"):
+            raise ValueError(f"Invalid activation function {activation_fn}")
+        if tvf_feature_sparsity > 0 or tvf_feature_window > 0:
+            raise NotImplementedError("TVF feature sparsity / windows (rl/models.py:389-421) are off by default and not built")
         _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -123,26 +177,41 @@ class DualHeadNet:
             raise _lib.PpoAmdError(f"device '{device}': the HIP path runs on the GPU only")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.spec = ImpalaSpec(input_dims, hidden_units=hidden_units, **encoder_args)
+        if encoder == "impala":
+            self.spec = ImpalaSpec(input_dims, hidden_units=hidden_units, **encoder_args)
+        else:
+            self.spec = MLPSpec(input_dims, hidden_units=hidden_units, **encoder_args)
+        self.encoder_kind = encoder
+        self.encoder_activation_fn = activation_fn
         self.n_actions = n_actions
         self.hidden_units = hidden_units
         self.value_head_names = list(value_head_names)
         self.vh = len(self.value_head_names)
         self.head_bias = head_bias
-        self.nh = 2 * n_actions + self.vh  # fused head rows: policy | value | advantage
+        self.tvf_fixed_head_horizons = None if tvf_fixed_head_horizons is None else list(tvf_fixed_head_horizons)
+        self.K = 0 if tvf_fixed_head_horizons is None else len(tvf_fixed_head_horizons)
+        # fused head columns
+        self.col_policy, self.col_value = 0, n_actions
+        self.col_advantage = n_actions + self.vh
+        self.col_tvf = 2 * n_actions + self.vh
+        self.nh = self.col_tvf + self.K * self.vh
         self._build_parameters(head_scale)
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._adam_step = 0
         self.exp_avg = None
         self.exp_avg_sq = None
 
+    @property
+    def use_tvf(self):
+        return self.K > 0
+
     # ------------------------------------------------------------------ parameters
     def _build_parameters(self, head_scale):
         sp = self.spec
-        init = init_impala_parameters(sp, self.n_actions, self.vh, head_scale, self.head_bias)
-        # physical order: encoder..., then the three head weights contiguous (one [nh, hidden] matrix),
-        # then the three head biases contiguous, then log_std
-        head_names = ("policy_head", "value_head", "advantage_head")
+        init = init_parameters(sp, self.n_actions, self.vh, head_scale, self.head_bias, self.K)
+        # physical order: encoder..., then the head weights contiguous (one [nh, hidden] matrix),
+        # then the head biases contiguous, then log_std
+        head_names = [n for n in HEAD_NAMES if f"{n}.weight" in init]
         order = [(n, t) for n, t in init.items() if n.startswith("encoder.")]
         order += [(f"{n}.weight", init[f"{n}.weight"]) for n in head_names]
         if self.head_bias:
@@ -165,6 +234,7 @@ class DualHeadNet:
         self.flat = flat.to(self.device)
         self.grad = torch.zeros_like(self.flat)
         self._offsets = offs
+        self._state_order = list(init.keys())
         self.params = OrderedDict((name, self.flat[o:o + int(np.prod(shape))].view(shape)) for name, (o, shape) in offs.items())
         self.grads = OrderedDict((name, self.grad[o:o + int(np.prod(shape))].view(shape)) for name, (o, shape) in offs.items())
         o = offs["policy_head.weight"][0]
@@ -182,7 +252,7 @@ class DualHeadNet:
 
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         """Reference key names (policy_net.<these>), tensors are views into the flat buffer."""
-        names = ["log_std"] + [n for n in self.params if n != "log_std"]
+        names = ["log_std"] + [n for n in self._state_order if n != "log_std"]
         return OrderedDict((n, self.params[n]) for n in names)
 
     def load_state_dict(self, sd, strict=True):
@@ -212,20 +282,62 @@ class DualHeadNet:
         if rc != 0:
             _lib.check(rc, fn_name)
 
+    def _linear(self, x, k, wname, out, relu_x=0):
+        """out[B, n] = f(x)[B, k] @ W[n, k]^T + b  (torch.nn.Linear)."""
+        w = self.params[wname + ".weight"]
+        B, n = x.shape[0], w.shape[0]
+        ws_bytes = self.lib.ppo_gemm_workspace_bytes(B, n, k)
+        ws = self._ws("gemm_ws", ws_bytes)
+        self._call("ppo_gemm_f32", _p(x), k, 1, relu_x, _p(w), 1, k, 0, _p(self.params[wname + ".bias"]), None,
+                   _p(out), n, B, n, k, _p(ws), ws_bytes)
+
+    def _linear_backward(self, x, k, wname, dy, dx, relu_x=0, mask=None, acc=0):
+        """dW = dy^T @ f(x), db = colsum(dy), dx = (dy @ W) [* (mask > 0)]  (dx nullable)."""
+        w = self.params[wname + ".weight"]
+        B, n = dy.shape[0], w.shape[0]
+        self._call("ppo_gemm_f32", _p(dy), 1, n, 0, _p(x), k, 1, relu_x, None, None, _p(self.grads[wname + ".weight"]), k,
+                   n, k, B, None, 0)
+        self._call("ppo_colsum_f32", _p(dy), B, n, n, _p(self.grads[wname + ".bias"]), acc)
+        if dx is not None:
+            self._call("ppo_gemm_f32", _p(dy), n, 1, 0, _p(w), k, 1, 0, None, _p(mask), _p(dx), k, B, k, n, None, 0)
+
     # ------------------------------------------------------------------ forward
     def _conv(self, x, mode, wname, out, residual, n, cin, cout, h, w):
         self._call("ppo_conv3x3_forward_f32", _p(x), mode, _p(self.params[wname + ".weight"]),
                    _p(self.params[wname + ".bias"]), _p(residual), _p(out), n, cin, cout, h, w)
 
     def encode(self, x: torch.Tensor, train: bool):
-        """x: [B, C, H, W] uint8 (scaled /255 on load) or float32.  Returns the dict of saved
-        pre-activation tensors; 'h' is the dense output before the encoder ReLU."""
+        """x: [B, *input_dims] uint8 (scaled /255 on load; impala only) or float32.  Returns the dict of
+        saved tensors; 'h' is the encoder output before the encoder activation, 'hact' its tanh when the
+        activation is tanh."""
         sp = self.spec
-        B = x.shape[0]
         if tuple(x.shape[1:]) != sp.input_dims:
             raise ValueError(f"expected input [B, {sp.input_dims}], got {tuple(x.shape)}")
         if x.dtype not in (torch.uint8, torch.float32) or not x.is_contiguous() or x.device != self.device:
             raise ValueError("input must be a contiguous uint8/float32 tensor on the model's device")
+        acts = self._encode_mlp(x, train) if self.encoder_kind == "mlp" else self._encode_impala(x, train)
+        if self.encoder_activation_fn == "tanh":
+            h = acts["h"]
+            hact = self._buf(("t" if train else "i") + "hact", tuple(h.shape))
+            self._call("ppo_tanh_forward_f32", _p(h), _p(hact), h.numel())
+            acts["hact"] = hact
+        return acts
+
+    def _encode_mlp(self, x, train):
+        if x.dtype != torch.float32:
+            raise ValueError("the mlp encoder takes float32 observations")
+        sp, B, tag = self.spec, x.shape[0], "t" if train else "i"
+        z1 = self._buf(f"{tag}z1", (B, sp.hidden_units))
+        self._linear(x, sp.in_features, "encoder.fc1", z1)
+        a1 = self._buf(f"{tag}a1", (B, sp.hidden_units))
+        self._call("ppo_tanh_forward_f32", _p(z1), _p(a1), z1.numel())
+        h = self._buf(f"{tag}h", (B, sp.hidden_units))
+        self._linear(a1, sp.hidden_units, "encoder.fc2", h)
+        return {"x": x, "a1": a1, "h": h}
+
+    def _encode_impala(self, x, train):
+        sp = self.spec
+        B = x.shape[0]
         tag = "t" if train else "i"
         acts = {"x": x}
         cur, cur_mode = x, (IN_U8 if x.dtype == torch.uint8 else IN_NONE)
@@ -248,81 +360,116 @@ class DualHeadNet:
             cur, cur_mode = q, IN_NONE
         flat = cur.view(B, sp.flat)
         h = self._buf(f"{tag}h", (B, sp.hidden_units))
-        wd = self.params["encoder.dense.weight"]
-        ws_bytes = self.lib.ppo_gemm_workspace_bytes(B, sp.hidden_units, sp.flat)
-        ws = self._ws("gemm_ws", ws_bytes)
-        self._call("ppo_gemm_f32", _p(flat), sp.flat, 1, 1, _p(wd), 1, sp.flat, 0,
-                   _p(self.params["encoder.dense.bias"]), None, _p(h), sp.hidden_units, B, sp.hidden_units, sp.flat,
-                   _p(ws), ws_bytes)
+        self._linear(flat, sp.flat, "encoder.dense", h, relu_x=1)
         acts["flat"], acts["h"] = flat, h
         return acts
 
-    def heads(self, h: torch.Tensor, tag="i"):
-        """[B, nh] = relu(h) @ [policy | value | advantage]^T (+ bias)  (rl/models.py:467-506)."""
+    def heads(self, acts, tag="i"):
+        """[B, nh] = act(h) @ [policy | value | advantage | tvf]^T (+ bias)  (rl/models.py:467-506).
+        `acts` is encode()'s dict (or, for relu nets, the pre-activation tensor h itself)."""
+        if isinstance(acts, dict):
+            h = acts.get("hact", acts["h"])
+        else:
+            h = acts
+            if self.encoder_activation_fn == "tanh":
+                raise ValueError("pass encode()'s dict: the tanh activation is computed there")
         B = h.shape[0]
         o = self._buf(f"{tag}heads", (B, self.nh))
-        self._call("ppo_gemm_f32", _p(h), self.hidden_units, 1, 1, _p(self.w_heads), 1, self.hidden_units, 0,
+        relu = 1 if self.encoder_activation_fn == "relu" else 0
+        self._call("ppo_gemm_f32", _p(h), self.hidden_units, 1, relu, _p(self.w_heads), 1, self.hidden_units, 0,
                    _p(self.b_heads), None, _p(o), self.nh, B, self.nh, self.hidden_units, None, 0)
         return o
 
-    def forward(self, x, policy_temperature: float = 1.0, train: bool = False) -> Dict[str, torch.Tensor]:
-        """Same result keys as the reference's DualHeadNet.forward (rl/models.py:433-508)."""
+    def forward(self, x, policy_temperature: float = 1.0, train: bool = False, exclude_value=False,
+                exclude_policy=False, exclude_tvf=False, include_features=False,
+                required_tvf_heads=None) -> Dict[str, torch.Tensor]:
+        """Same result keys as the reference's DualHeadNet.forward (rl/models.py:433-508).  Value-like
+        entries are views of the fused head row (strided, not copies)."""
         acts = self.encode(x, train)
-        o = self.heads(acts["h"], "t" if train else "i")
+        o = self.heads(acts, "t" if train else "i")
         B, nA = o.shape[0], self.n_actions
-        logp = self._buf("log_policy", (B, nA))
-        result = {"raw_policy": o[:, :nA], "value": o[:, nA:nA + self.vh], "advantage": o[:, nA + self.vh:]}
-        if policy_temperature > 0:
-            self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, float(policy_temperature), None, 0, 0, 1, _p(logp),
-                       None, None, None, None, self.vh)
-            result["log_policy"] = logp
-        else:
-            # greedy / blended policy (rl/models.py:475-485): tiny [B, nA] tensors, composed from the
-            # HIP log-softmax and argmax
-            act = self._buf("greedy_actions", (B,), torch.int32)
-            self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, 1.0, None, 0, 0, 1, _p(logp), _p(act), None,
-                       None, None, self.vh)
-            argmax_policy = torch.zeros_like(logp)
-            argmax_policy[torch.arange(B, device=self.device), act.long()] = 1.0
-            eps = 1 + policy_temperature
-            result["log_policy"] = torch.log(eps * argmax_policy + (1 - eps) * torch.exp(logp) + 1e-8)
-            result["argmax_policy"] = argmax_policy
+        result = {}
+        if include_features:
+            result["raw_features"] = acts["h"]
+            result["features"] = acts["hact"] if "hact" in acts else torch.relu(acts["h"])
+        if not exclude_policy:
+            logp = self._buf("log_policy", (B, nA))
+            result["raw_policy"] = o[:, :nA]
+            if nA > 32:
+                pass  # wide gaussian policies have no log_softmax (rl/rollout.py uses raw_policy only)
+            elif policy_temperature > 0:
+                self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, float(policy_temperature), None, 0, 0, 1,
+                           _p(logp), None, None, None, None, self.vh)
+                result["log_policy"] = logp
+            else:
+                # greedy / blended policy (rl/models.py:475-485): tiny [B, nA] tensors, composed from the
+                # HIP log-softmax and argmax
+                act = self._buf("greedy_actions", (B,), torch.int32)
+                self._call("ppo_policy_act_f32", _p(o), B, self.nh, nA, 1.0, None, 0, 0, 1, _p(logp), _p(act), None,
+                           None, None, self.vh)
+                argmax_policy = torch.zeros_like(logp)
+                argmax_policy[torch.arange(B, device=self.device), act.long()] = 1.0
+                eps = 1 + policy_temperature
+                result["log_policy"] = torch.log(eps * argmax_policy + (1 - eps) * torch.exp(logp) + 1e-8)
+                result["argmax_policy"] = argmax_policy
+        if not exclude_value:
+            result["value"] = o[:, self.col_value:self.col_value + self.vh]
+            if self.use_tvf and not exclude_tvf:
+                tvf = o[:, self.col_tvf:].view(B, self.K, self.vh)
+                result["tvf_value"] = tvf if required_tvf_heads is None else tvf[:, required_tvf_heads]
+        result["advantage"] = o[:, self.col_advantage:self.col_advantage + nA]
         result["_heads"], result["_acts"] = o, acts
         return result
 
     # ------------------------------------------------------------------ backward
     def backward(self, acts, dheads: torch.Tensor, accumulate: bool = False):
-        """Back-propagate d loss / d heads through heads, dense layer and encoder into self.grad."""
-        sp, lib = self.spec, self.lib
+        """Back-propagate d loss / d heads through heads and encoder into self.grad."""
+        sp = self.spec
         B = dheads.shape[0]
         H = sp.hidden_units
-        acc = 1 if accumulate else 0
         if accumulate:
-            raise NotImplementedError("gradient accumulation over micro-batches is not wired for the GEMM layers yet")
-        h, flat = acts["h"], acts["flat"]
-        # heads: dW = dheads^T @ relu(h); db = colsum(dheads); dh = (dheads @ W) * (h > 0)
-        self._call("ppo_gemm_f32", _p(dheads), 1, self.nh, 0, _p(h), H, 1, 1, None, None, _p(self.g_w_heads), H,
-                   self.nh, H, B, None, 0)
+            raise NotImplementedError("micro-batch gradient accumulation is not built: with 288 GB of HBM a whole "
+                                      "minibatch is one pass (rl/rollout.py:2331-2374 splits only to fit memory)")
+        h = acts["h"]
+        relu = self.encoder_activation_fn == "relu"
+        hin = h if relu else acts["hact"]
+        # heads: dW = dheads^T @ act(h); db = colsum(dheads); dh = (dheads @ W) * act'(h)
+        self._call("ppo_gemm_f32", _p(dheads), 1, self.nh, 0, _p(hin), H, 1, 1 if relu else 0, None, None,
+                   _p(self.g_w_heads), H, self.nh, H, B, None, 0)
         if self.head_bias:
-            self._call("ppo_colsum_f32", _p(dheads), B, self.nh, self.nh, _p(self.g_b_heads), acc)
+            self._call("ppo_colsum_f32", _p(dheads), B, self.nh, self.nh, _p(self.g_b_heads), 0)
         dh = self._buf("dh", (B, H))
-        self._call("ppo_gemm_f32", _p(dheads), self.nh, 1, 0, _p(self.w_heads), H, 1, 0, None, _p(h), _p(dh), H, B, H,
-                   self.nh, None, 0)
+        self._call("ppo_gemm_f32", _p(dheads), self.nh, 1, 0, _p(self.w_heads), H, 1, 0, None, _p(h) if relu else None,
+                   _p(dh), H, B, H, self.nh, None, 0)
+        if not relu:
+            self._call("ppo_tanh_backward_f32", _p(dh), _p(hin), _p(dh), dh.numel())
+        if self.encoder_kind == "mlp":
+            self._backward_mlp(acts, dh)
+        else:
+            self._backward_impala(acts, dh)
+
+    def _backward_mlp(self, acts, dh):
+        sp = self.spec
+        B, H = dh.shape
+        da1 = self._buf("da1", (B, H))
+        self._linear_backward(acts["a1"], H, "encoder.fc2", dh, da1)
+        self._call("ppo_tanh_backward_f32", _p(da1), _p(acts["a1"]), _p(da1), da1.numel())
+        self._linear_backward(acts["x"], sp.in_features, "encoder.fc1", da1, None)
+
+    def _backward_impala(self, acts, dh):
+        sp, lib = self.spec, self.lib
+        B, H = dh.shape
+        flat = acts["flat"]
         # dense: dW = dh^T @ relu(flat); db = colsum(dh); dflat = (dh @ W) * (flat > 0)
-        wd = self.params["encoder.dense.weight"]
-        self._call("ppo_gemm_f32", _p(dh), 1, H, 0, _p(flat), sp.flat, 1, 1, None, None,
-                   _p(self.grads["encoder.dense.weight"]), sp.flat, H, sp.flat, B, None, 0)
-        self._call("ppo_colsum_f32", _p(dh), B, H, H, _p(self.grads["encoder.dense.bias"]), acc)
         c_last, h_last, w_last = sp.out_shape
         g = self._buf(f"g{len(sp.stacks) - 1}_a", (B, c_last, h_last, w_last))
-        self._call("ppo_gemm_f32", _p(dh), H, 1, 0, _p(wd), sp.flat, 1, 0, None, _p(flat), _p(g), sp.flat, B, sp.flat,
-                   H, None, 0)
+        self._linear_backward(flat, sp.flat, "encoder.dense", dh, g, relu_x=1, mask=flat)
 
         def wgrad(x, mode, dy, wname, n, cin, cout, hh, ww):
             nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
             ws = self._ws("wgrad_ws", nbytes)
             self._call("ppo_conv3x3_backward_weight_f32", _p(x), mode, _p(dy), _p(self.grads[wname + ".weight"]),
-                       _p(self.grads[wname + ".bias"]), _p(ws), nbytes, n, cin, cout, hh, ww, acc)
+                       _p(self.grads[wname + ".bias"]), _p(ws), nbytes, n, cin, cout, hh, ww, 0)
 
         for si in reversed(range(len(sp.stacks))):
             cin, cout, hh, ww, ho, wo = sp.stacks[si]
@@ -352,36 +499,93 @@ class DualHeadNet:
                 self._call("ppo_conv3x3_backward_data_f32", _p(dc), _p(self.params[f"encoder.stacks.{si}.firstconv.weight"]),
                            None, None, _p(g), B, cin, cout, hh, ww)
 
-    # ------------------------------------------------------------------ PPO minibatch + optimiser
+    # ------------------------------------------------------------------ minibatch losses + optimiser
+    def _train_forward(self, prev_state):
+        acts = self.encode(prev_state, train=True)
+        o = self.heads(acts, "t")
+        B = o.shape[0]
+        return acts, o, B, self._buf("dheads", (B, self.nh))
+
     def ppo_minibatch(self, prev_state, actions, old_log_pac, old_log_policy, advantages, returns,
                       eps_clip=0.2, ent_coef=0.01, vf_coef=0.5, loss_scale=1.0, index=None):
         """Forward, fused PPO loss, backward: gradients of mean(-gain)*loss_scale land in self.grad
-        (Runner.train_policy_minibatch, rl/rollout.py:1610-1771, single architecture).
+        (Runner.train_policy_minibatch, rl/rollout.py:1610-1771; discrete actions).  vf_coef = 0 (and
+        returns None) leaves the value head out, as the dual architecture's policy phase does (:1744).
         prev_state is the (already gathered) minibatch of observations; the per-sample arrays are
         either minibatch-sized or, with ``index`` ([B] int32), whole-batch arrays read at index[b].
         Returns the per-sample statistics tensor [B, 8] (device)."""
-        acts = self.encode(prev_state, train=True)
-        o = self.heads(acts["h"], "t")
-        B = o.shape[0]
-        dheads = self._buf("dheads", (B, self.nh))
+        acts, o, B, dheads = self._train_forward(prev_state)
         stats = self._buf("loss_stats", (B, 8))
-        self._call("ppo_ppo_loss_f32", _p(o), B, self.nh, self.n_actions, self.vh, _p(actions), _p(old_log_pac),
+        vh = self.vh if returns is not None else 0
+        self._call("ppo_ppo_loss_f32", _p(o), B, self.nh, self.n_actions, vh, _p(actions), _p(old_log_pac),
                    _p(old_log_policy), _p(advantages), _p(returns), float(eps_clip), float(ent_coef), float(vf_coef),
                    float(loss_scale) / B, _p(dheads), _p(stats), _p(index))
         self.backward(acts, dheads)
         return stats
 
+    def gaussian_minibatch(self, prev_state, actions, old_log_pac, advantages, returns, eps_clip=0.2, vf_coef=0.5,
+                           loss_scale=1.0, index=None):
+        """As ppo_minibatch for gaussian policies (rl/rollout.py:1693-1704); also fills log_std's gradient."""
+        acts, o, B, dheads = self._train_forward(prev_state)
+        stats = self._buf("loss_stats", (B, 8))
+        rows = self._buf("dlog_std_rows", (B, self.n_actions))
+        vh = self.vh if returns is not None else 0
+        self._call("ppo_gaussian_loss_f32", _p(o), B, self.nh, self.n_actions, vh, _p(actions), _p(old_log_pac),
+                   _p(advantages), _p(returns), _p(self.params["log_std"]), float(eps_clip), float(vf_coef),
+                   float(loss_scale) / B, _p(dheads), _p(rows), _p(stats), _p(index))
+        self.backward(acts, dheads)
+        self._call("ppo_colsum_f32", _p(rows), B, self.n_actions, self.n_actions, _p(self.grads["log_std"]), 0)
+        return stats
+
+    def value_minibatch(self, prev_state, returns=None, tvf_returns=None, tvf_weights=None, vf_coef=0.5,
+                        tvf_coef=1.0, loss_scale=1.0, index=None):
+        """Value phase (Runner.train_value_minibatch, rl/rollout.py:1513-1567; TVF loss rl/tvf.py:32-77)."""
+        acts, o, B, dheads = self._train_forward(prev_state)
+        stats = self._buf("value_stats", (B, 4))
+        self._call("ppo_value_loss_f32", _p(o), B, self.nh, self.col_value, self.vh if returns is not None else 0,
+                   _p(returns), float(vf_coef), self.col_tvf if self.K else 0, self.K if tvf_returns is not None else 0,
+                   max(self.vh, 1), _p(tvf_returns), _p(tvf_weights), float(tvf_coef), float(loss_scale) / B, _p(dheads),
+                   _p(stats), _p(index))
+        self.backward(acts, dheads)
+        return stats
+
+    def distil_minibatch(self, prev_state, targets, old_policy, beta=1.0, use_tvf=False, weights=None, gaussian=False,
+                         loss_scale=1.0, index=None):
+        """Distillation phase (Runner.train_distil_minibatch, rl/rollout.py:1331-1449): targets [*] against the
+        ext value head, or [*, K] against the TVF heads' ext column (use_tvf)."""
+        acts, o, B, dheads = self._train_forward(prev_state)
+        stats = self._buf("distil_stats", (B, 4))
+        col, n_pred, stride = (self.col_tvf, self.K, self.vh) if use_tvf else (self.col_value, 1, 1)
+        self._call("ppo_distil_loss_f32", _p(o), B, self.nh, self.n_actions, col, n_pred, stride, 1 if use_tvf else 0,
+                   _p(targets), _p(weights), _p(old_policy), _p(self.params["log_std"]) if gaussian else None,
+                   float(beta), float(loss_scale) / B, _p(dheads), _p(stats), _p(index))
+        self.backward(acts, dheads)
+        return stats
+
+    def zero_untouched_grads(self):
+        """log_std only receives gradient from the gaussian policy loss; every other parameter is overwritten
+        by each backward.  Called by phases that do not touch log_std so a stale gradient never leaks."""
+        self.grads["log_std"].zero_()
+
     def adam_step(self, lr=2.5e-4, beta1=0.9, beta2=0.999, eps=1e-5, max_grad_norm=20.0, grad_div=1.0,
-                  grad_norm_out: Optional[torch.Tensor] = None):
-        """clip_grad_norm_ + torch.optim.Adam.step over the flat buffer (rl/rollout.py:1287-1321)."""
-        if self.exp_avg is None:
-            self.exp_avg = torch.zeros_like(self.flat)
-            self.exp_avg_sq = torch.zeros_like(self.flat)
-        self._adam_step += 1
+                  grad_norm_out: Optional[torch.Tensor] = None, state: Optional["AdamState"] = None):
+        """clip_grad_norm_ + torch.optim.Adam.step over the flat buffer (rl/rollout.py:1287-1321).
+        `state`: a separate set of Adam moments over the same parameters (the reference's distil optimiser,
+        rl/rollout.py:136-141); default is the net's own."""
         ws = self._ws("adam_ws", self.lib.ppo_adam_workspace_bytes())
-        self._call("ppo_adam_step_f32", _p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq),
-                   self.flat.numel(), self._adam_step, float(lr), float(beta1), float(beta2), float(eps),
-                   float(max_grad_norm), float(grad_div), _p(ws), _p(grad_norm_out))
+        if state is not None:
+            state.ensure(self.flat)
+            state.step += 1
+            m, v, step = state.exp_avg, state.exp_avg_sq, state.step
+        else:
+            if self.exp_avg is None:
+                self.exp_avg = torch.zeros_like(self.flat)
+                self.exp_avg_sq = torch.zeros_like(self.flat)
+            self._adam_step += 1
+            m, v, step = self.exp_avg, self.exp_avg_sq, self._adam_step
+        self._call("ppo_adam_step_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step, float(lr),
+                   float(beta1), float(beta2), float(eps), float(max_grad_norm), float(grad_div), _p(ws),
+                   _p(grad_norm_out))
 
     # ------------------------------------------------------------------ optimiser state (checkpoints)
     def optimizer_state_dict(self):
@@ -411,10 +615,10 @@ class DualHeadNet:
 
 
 class TVFModel:
-    """Host mirror of the reference's TVFModel (rl/models.py:511-856) for the PPO path: owns
-    `policy_net` (and, for `architecture='single'`, `value_net is policy_net`), exposes
-    `forward(x, output=..., policy_temperature=...) -> dict` with the reference's key aliasing
-    (:790-796) and a `state_dict` with the reference's `policy_net.` / `value_net.` prefixes."""
+    """Host mirror of the reference's TVFModel (rl/models.py:511-856): owns `policy_net` and `value_net`
+    (the same object for `architecture='single'`, two nets for 'dual'), exposes
+    `forward(x, output=..., policy_temperature=...) -> dict` with the reference's routing and key aliasing
+    (:790-821) and a `state_dict` with the reference's `policy_net.` / `value_net.` prefixes."""
 
     def __init__(self, encoder: str, encoder_args=None, input_dims=(4, 84, 84), actions: int = 6, device="cuda",
                  architecture: str = "dual", dtype=torch.float32, use_rnd: bool = False, hidden_units: int = 512,
@@ -423,10 +627,10 @@ class TVFModel:
                  tvf_feature_sparsity: float = 0.0, tvf_feature_window: int = -1, head_scale: float = 1.0,
                  value_head_names=("ext",), norm_eps: float = 1e-5, head_bias: bool = False,
                  observation_scaling: str = "scaled"):
-        if architecture != "single":
-            raise NotImplementedError("HIP path: architecture='single' (PPO). 'dual' (DNA) is listed as next in DESIGN.md")
-        if use_rnd or observation_normalization or tvf_fixed_head_horizons is not None:
-            raise NotImplementedError("RND / observation normalisation / TVF heads are not on the HIP path yet")
+        if architecture not in ("single", "dual"):
+            raise Exception("Invalid architecture, use [dual|single]")
+        if use_rnd or observation_normalization:
+            raise NotImplementedError("RND / observation normalisation are outside the PPO hot path (DESIGN.md)")
         if dtype != torch.float32:
             raise ValueError("the reference path is float32 (rl/models.py:31-32)")
         if observation_scaling != "scaled":
@@ -436,20 +640,30 @@ class TVFModel:
             encoder_args = ast.literal_eval(encoder_args)
         self.input_dims = tuple(input_dims)
         self.actions = actions
-        self.device = device
         self.dtype = dtype
         self.architecture = architecture
         self.encoder_name = encoder
-        self.name = "PPO-" + encoder
-        self.policy_net = DualHeadNet(encoder, input_dims, actions, hidden_units=hidden_units,
-                                      activation_fn=encoder_activation_fn, head_scale=head_scale,
-                                      value_head_names=value_head_names, head_bias=head_bias, device=device,
-                                      **(encoder_args or {}))
-        self.value_net = self.policy_net
+        self.tvf_fixed_head_horizons = tvf_fixed_head_horizons
+        self.tvf_fixed_head_weights = tvf_fixed_head_weights
+        if architecture == "single":
+            self.name = "PPO-" + encoder
+        else:
+            self.name = ("TVF-" if tvf_fixed_head_horizons is not None else "DNA-") + encoder
+
+        def make_net():
+            return DualHeadNet(encoder, input_dims, actions, hidden_units=hidden_units,
+                               activation_fn=encoder_activation_fn, tvf_fixed_head_horizons=tvf_fixed_head_horizons,
+                               tvf_feature_sparsity=tvf_feature_sparsity, tvf_feature_window=tvf_feature_window,
+                               head_scale=head_scale, value_head_names=value_head_names, head_bias=head_bias,
+                               device=device, **(encoder_args or {}))
+
+        self.policy_net = make_net()
+        self.value_net = make_net() if architecture == "dual" else self.policy_net
         self.device = self.policy_net.device
 
     def model_size(self, trainable_only: bool = True):
-        return self.policy_net.n_parameters()
+        n = self.policy_net.n_parameters()
+        return n if self.architecture == "single" else n + self.value_net.n_parameters()
 
     def prep_for_model(self, x):
         """rl/models.py:824-856: accept ndarray or tensor, uint8 or float; the /255 scaling itself is fused
@@ -465,14 +679,31 @@ class TVFModel:
     def forward(self, x, output: str = "default", policy_temperature: float = 1.0, include_rnd=False,
                 include_features=False, update_normalization=False, **kwargs):
         assert output in ["default", "full", "policy", "value"]
-        out = self.policy_net.forward(self.prep_for_model(x), policy_temperature=policy_temperature)
+        x = self.prep_for_model(x)
+        net_args = dict(policy_temperature=policy_temperature, include_features=include_features, **kwargs)
+
+        def public(d):
+            return {k: (v.clone() if self.architecture == "dual" else v) for k, v in d.items() if not k.startswith("_")}
+
         result = {}
-        for k, v in out.items():
-            if k.startswith("_"):
-                continue
-            result["policy_" + k] = v
-            result["value_" + k] = v
-            result[k] = v
+        if self.architecture == "single":
+            for k, v in public(self.policy_net.forward(x, **net_args)).items():
+                result["policy_" + k] = v
+                result["value_" + k] = v
+                result[k] = v
+            return result
+        # dual: head rows live in per-net scratch that the next forward of that net reuses, so results are
+        # cloned (small [B, heads] tensors)
+        if output == "full":
+            for k, v in public(self.policy_net.forward(x, **net_args)).items():
+                result["policy_" + k] = v
+            for k, v in public(self.value_net.forward(x, **net_args)).items():
+                result["value_" + k] = v
+            return result
+        if output in ("default", "policy"):
+            result.update(public(self.policy_net.forward(x, **net_args, exclude_value=output == "default")))
+        if output in ("default", "value"):
+            result.update(public(self.value_net.forward(x, **net_args, exclude_policy=output == "default")))
         return result
 
     __call__ = forward
@@ -480,13 +711,27 @@ class TVFModel:
     def log_policy(self, x):
         return self.forward(x, output="policy")["log_policy"].detach().cpu().numpy()
 
+    def adjust_value_scale(self, factor: float, process_value=True, process_tvf=True, value_net_only=False):
+        """rl/models.py:630-651: scale value predictions by scaling the value / TVF head weights and biases."""
+        nets = [self.value_net] if value_net_only else ([self.policy_net] if self.architecture == "single" else
+                                                        [self.policy_net, self.value_net])
+        for net in nets:
+            names = (["value_head"] if process_value else []) + (["tvf_head"] if process_tvf and net.use_tvf else [])
+            for n in names:
+                net.params[n + ".weight"].mul_(factor)
+                if net.head_bias:
+                    net.params[n + ".bias"].mul_(factor)
+
     def state_dict(self):
         sd = OrderedDict()
-        for prefix in ("policy_net.", "value_net."):
-            for k, v in self.policy_net.state_dict().items():
+        for prefix, net in (("policy_net.", self.policy_net), ("value_net.", self.value_net)):
+            for k, v in net.state_dict().items():
                 sd[prefix + k] = v
         return sd
 
     def load_state_dict(self, sd, strict=True):
         pol = {k[len("policy_net."):]: v for k, v in sd.items() if k.startswith("policy_net.")}
         self.policy_net.load_state_dict(pol, strict=strict)
+        if self.architecture == "dual":
+            val = {k[len("value_net."):]: v for k, v in sd.items() if k.startswith("value_net.")}
+            self.value_net.load_state_dict(val, strict=strict)

@@ -54,7 +54,7 @@ def train(model, log: Logger):
     final_epoch = min(args.epochs, args.limit_epochs) if args.limit_epochs is not None else args.epochs
     end_iteration = math.ceil((final_epoch * 1e6) / batch_size)
 
-    runner = Runner(model, log, action_dist="discrete")
+    runner = Runner(model, log, action_dist="gaussian" if args.env.type == "mujoco" else "discrete")
     runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
     runner.reset()
     log.important("Generated {} agents x {} rank(s) using {} ({:.2f}M params) model.".format(

@@ -1,45 +1,75 @@
-"""Rollout runner — host mirror of the reference's rl/rollout.py `Runner` for the PPO hot path
-(`--model_architecture=single`): `generate_rollout` (:702-969), `calculate_returns` (:1182-1285),
-`train` / `train_policy` / `train_batch` (:2220-2255, :1853-1953, :2257-2407), `optimizer_step`
-(:1287-1321).
+"""Rollout runner — host mirror of the reference's rl/rollout.py `Runner`: `generate_rollout` (:702-969),
+`calculate_returns` (:1182-1285), `train` (:2220-2255) with its policy / value / distil phases
+(`train_policy` :1853-1953, `train_value` :1956-2004, `train_distil` :2140-2164), the minibatch functions
+(:1331-1449, :1513-1567, :1610-1771), `train_batch` (:2257-2407) and `optimizer_step` (:1287-1321), for
+`--model_architecture=single` (PPO) and `dual` (DNA / TVF), discrete and gaussian action distributions.
 
 What changed relative to the reference, and why (MI355X-first):
-  * every rollout buffer lives in HBM (`all_obs` uint8 [N+1, A, C, H, W], `value`, `log_policy`,
-    `actions`, rewards, terminals ...); the reference keeps them in host NumPy arrays and re-uploads
-    minibatches (rl/rollout.py:189-250, 2349-2372);
-  * one device->host copy per env step (the sampled actions) instead of five (:641, 809-813);
-    action sampling (Gumbel-max) runs on the GPU next to the policy head;
-  * GAE + lambda-returns are one fused HIP scan; advantage normalisation, the minibatch gather,
-    the PPO loss, backward and Adam are HIP kernels (ppo_amd/csrc);
+  * every rollout buffer lives in HBM (`all_obs` [N+1, A, ...], `value`, `log_policy`, `actions`, rewards,
+    terminals, TVF values ...); the reference keeps them in host NumPy arrays and re-uploads minibatches
+    (rl/rollout.py:189-250, 2349-2372);
+  * one device->host copy per env step (the sampled actions) instead of five (:641, 809-813); action
+    sampling (Gumbel-max / gaussian) runs on the GPU next to the policy head; with array-stepping envs the
+    step is software-pipelined over two env groups;
+  * GAE + lambda-returns are one fused HIP scan, TVF returns one HIP kernel; advantage normalisation, the
+    minibatch gather, every loss, backward and Adam are HIP kernels (ppo_amd/csrc); minibatches are read
+    through an index vector instead of being gathered (only the observations are gathered);
   * statistics are reduced on the device and fetched once per iteration;
-  * data parallelism: env columns are sharded over ranks (one process per GPU); the only exchanges
-    are one RCCL all-reduce of the flat gradient per optimiser step and one of the three advantage
-    moments per batch, so an N-GPU run equals a 1-GPU run with N*A envs up to minibatch composition.
+  * data parallelism: env columns are sharded over ranks (one process per GPU); the only exchanges are one
+    RCCL all-reduce of the flat gradient per optimiser step and one of the three advantage moments per
+    batch, so an N-GPU run equals a 1-GPU run with N*A envs up to minibatch composition.
 """
-import time
-
 import numpy as np
 import torch
 
 from . import _lib, parallel
 from .config import args
+from .models import AdamState
 
 
 def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class Optimizer:
+    """What the reference's `self.policy_optimizer` etc. stand for here: a net's flat parameter buffer, one
+    set of Adam moments over it and the flag group with its hyper-parameters (rl/rollout.py:126-141)."""
+
+    def __init__(self, net, cfg, state=None):
+        self.net, self.cfg, self.state = net, cfg, state
+
+    def zero_grad(self, set_to_none=True):
+        self.net.grad.zero_()
+
+    def state_dict(self):
+        if self.state is None:
+            return self.net.optimizer_state_dict()
+        if self.state.exp_avg is None:
+            return {"step": 0, "state": {}}
+        return {"step": self.state.step, "flat": {"exp_avg": self.state.exp_avg.clone(),
+                                                  "exp_avg_sq": self.state.exp_avg_sq.clone()}, "state": {}}
+
+    def load_state_dict(self, sd):
+        if self.state is None:
+            self.net.load_optimizer_state_dict(sd)
+        elif "flat" in sd:
+            self.state.ensure(self.net.flat)
+            self.state.step = int(sd["step"])
+            self.state.exp_avg.copy_(sd["flat"]["exp_avg"])
+            self.state.exp_avg_sq.copy_(sd["flat"]["exp_avg_sq"])
+
+
 class Runner:
     def __init__(self, model, log, name="agent", action_dist="discrete"):
-        if action_dist != "discrete":
-            raise NotImplementedError("the HIP path implements the discrete-action PPO update")
-        if args.model.architecture != "single":
-            raise NotImplementedError("Runner here implements --model_architecture=single (PPO); see DESIGN.md")
+        if action_dist not in ("discrete", "gaussian"):
+            raise ValueError(f"Invalid distribution {action_dist}")
         _lib.require_gpu()
         self.lib = _lib.load()
         self.name = name
         self.model = model
-        self.net = model.policy_net
+        self.policy_net, self.value_net = model.policy_net, model.value_net
+        self.net = self.policy_net
+        self.dual = model.architecture == "dual"
         self.log = log
         self.action_dist = action_dist
         self.device = self.net.device
@@ -50,31 +80,50 @@ class Runner:
         self.state_shape = tuple(model.input_dims)
         self.n_actions = model.actions
         self.VH = self.net.vh
+        if self.VH != 1:
+            raise NotImplementedError("one extrinsic value head on this path (intrinsic rewards are out of scope)")
         self.world, self.rank = parallel.world_size(), parallel.rank()
         N, A, nA, VH, dev = self.N, self.A, self.n_actions, self.VH, self.device
-        obs_dtype = torch.float32 if args.env.type == "mujoco" else torch.uint8
+        gaussian = action_dist == "gaussian"
+        obs_dtype = torch.uint8 if model.policy_net.encoder_kind == "impala" and args.env.type != "mujoco" else torch.float32
         # ---- rollout buffers, all resident in HBM (time-major, env index contiguous)
         self.all_obs = torch.zeros((N + 1, A, *self.state_shape), dtype=obs_dtype, device=dev)
         self.value = torch.zeros((N + 1, A, VH), dtype=torch.float32, device=dev)
         self.returns = torch.zeros((N, A, VH), dtype=torch.float32, device=dev)
-        self.actions = torch.zeros((N, A), dtype=torch.int32, device=dev)
+        if gaussian:
+            self.actions = torch.zeros((N, A, nA), dtype=torch.float32, device=dev)
+            self.log_pac = torch.zeros((N, A, nA), dtype=torch.float32, device=dev)
+        else:
+            self.actions = torch.zeros((N, A), dtype=torch.int32, device=dev)
+            self.log_pac = torch.zeros((N, A), dtype=torch.float32, device=dev)
         self.ext_rewards = torch.zeros((N, A), dtype=torch.float32, device=dev)
         self.log_policy = torch.zeros((N, A, nA), dtype=torch.float32, device=dev)
         self.raw_policy = torch.zeros((N, A, nA), dtype=torch.float32, device=dev)
-        self.log_pac = torch.zeros((N, A), dtype=torch.float32, device=dev)
         self.terminals = torch.zeros((N, A), dtype=torch.bool, device=dev)
         self.advantage = torch.zeros((N, A), dtype=torch.float32, device=dev)
         self.raw_advantage = self.advantage
         self.norm_advantage = torch.zeros((N, A), dtype=torch.float32, device=dev)
         # ---- host staging (pinned): one step of actions down, a whole rollout of rewards/dones up
-        self._actions_host = torch.zeros(A, dtype=torch.int32).pin_memory()
+        self._actions_host = torch.zeros((A, nA) if gaussian else (A,),
+                                         dtype=torch.float32 if gaussian else torch.int32).pin_memory()
         self._rewards_host = torch.zeros((N, A), dtype=torch.float32).pin_memory()
         self._dones_host = torch.zeros((N, A), dtype=torch.uint8).pin_memory()
-        self.obs = None  # current observation (host, pinned), set by reset()
+        self.obs = None  # current observation (host), set by reset()
         self.time = np.zeros(A, np.int32)
         self.episode_score = np.zeros(A, np.float32)
         self.episode_len = np.zeros(A, np.int32)
         self.ep_count = 0
+        # ---- TVF (rl/rollout.py:311-313)
+        self.tvf = None
+        if model.tvf_fixed_head_horizons is not None:
+            from .tvf import TVFRunnerModule
+            self.tvf = TVFRunnerModule(self)
+            self._tvf_weights_dev = torch.as_tensor(np.asarray(self.tvf_weights, np.float32), device=dev)
+            self._ext_estimate = torch.zeros((N + 1, A), dtype=torch.float32, device=dev)
+        # ---- optimisers (rl/rollout.py:126-141)
+        self.policy_optimizer = Optimizer(self.policy_net, args.policy_opt)
+        self.value_optimizer = Optimizer(self.value_net, args.value_opt) if self.dual else self.policy_optimizer
+        self.distil_optimizer = Optimizer(self.policy_net, args.distil_opt, AdamState()) if self.dual else None
         # ---- device scratch
         self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
         self._moments_ws = torch.zeros(self.lib.ppo_moments_workspace_bytes() // 8, dtype=torch.float64, device=dev)
@@ -82,7 +131,7 @@ class Runner:
         self._grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sample_calls = 0
         self._step_events = []
-        self._stat_rows = None
+        self._phase_stats = {}
         self.timers = {}
 
     # ------------------------------------------------------------------ helpers
@@ -96,6 +145,10 @@ class Runner:
         return self.value[:, :, 0]
 
     @property
+    def ext_returns(self):
+        return self.returns[:, :, 0]
+
+    @property
     def prev_obs(self):
         return self.all_obs[:-1]
 
@@ -106,6 +159,26 @@ class Runner:
     @property
     def current_entropy_bonus(self):
         return args.entropy_bonus
+
+    @property
+    def value_heads(self):
+        return ["ext"]
+
+    @property
+    def tvf_horizons(self):
+        return self.model.tvf_fixed_head_horizons
+
+    @property
+    def tvf_weights(self):
+        """Loss weight per TVF head: duplicates removed when spacing the heads (rl/rollout.py:1323-1328)."""
+        return np.asarray(self.model.tvf_fixed_head_weights, dtype=np.float32).copy()
+
+    @property
+    def K(self):
+        return len(self.tvf_horizons)
+
+    def get_current_actions_std(self):
+        return 0.0 if self.action_dist == "discrete" else torch.exp(self.policy_net.params["log_std"])
 
     def reset(self):
         """rl/rollout.py:520-556: reset envs and per-env bookkeeping."""
@@ -120,19 +193,34 @@ class Runner:
     def _policy_step(self, t, lo=0, hi=None):
         """Forward + action sampling for envs [lo, hi) at env step t; writes those columns of row t of the
         rollout buffers.  The sampling counter is keyed by (rollout, t, env, action), so splitting the envs
-        into groups does not change which action any env takes."""
-        net = self.net
+        into groups does not change which action any env takes.  Dual architecture: the policy comes from
+        policy_net, value (and TVF) estimates from value_net (rl/models.py:809-821)."""
+        pol, val = self.policy_net, self.value_net
         hi = self.A if hi is None else hi
-        acts = net.encode(self.all_obs[t, lo:hi], train=False)
-        heads = net.heads(acts["h"], "i")
+        B = hi - lo
+        obs = self.all_obs[t, lo:hi]
+        hp = pol.heads(pol.encode(obs, train=False), "i")
+        hv = val.heads(val.encode(obs, train=False), "i") if self.dual else hp
         A, nA = self.A, self.n_actions
         final = t >= self.N
         seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + self.rank
         counter = ((self._sample_calls + t) * A + lo) * nA
-        self._call("ppo_policy_act_f32", _p(heads), hi - lo, net.nh, nA, 1.0, None, seed & (2**64 - 1), counter, 0,
-                   None if final else _p(self.log_policy[t, lo:hi]), None if final else _p(self.actions[t, lo:hi]),
-                   None if final else _p(self.log_pac[t, lo:hi]), None if final else _p(self.raw_policy[t, lo:hi]),
-                   _p(self.value[t, lo:hi]), self.VH)
+        values = None if self.dual else _p(self.value[t, lo:hi])
+
+        def row(buf):
+            return None if final else _p(buf[t, lo:hi])
+
+        if self.action_dist == "discrete":
+            self._call("ppo_policy_act_f32", _p(hp), B, pol.nh, nA, 1.0, None, seed & (2**64 - 1), counter, 0,
+                       row(self.log_policy), row(self.actions), row(self.log_pac), row(self.raw_policy), values, self.VH)
+        else:
+            self._call("ppo_gaussian_act_f32", _p(hp), B, pol.nh, nA, _p(pol.params["log_std"]), None,
+                       seed & (2**64 - 1), counter, 0, row(self.actions), row(self.log_pac), row(self.raw_policy),
+                       values, self.VH)
+        if self.dual:
+            self.value[t, lo:hi].copy_(hv[:, val.col_value:val.col_value + self.VH])
+        if self.tvf is not None:
+            self.tvf.tvf_value[t, lo:hi].copy_(hv[:, val.col_tvf:].view(B, val.K, self.VH))
 
     def _log_finished(self, finished, ep_len, ep_score):
         if finished.any():
@@ -215,16 +303,32 @@ class Runner:
             self._log_finished(np.asarray(dones, bool), np.asarray([i.get("ep_length", 0) for i in infos]),
                                np.asarray([i.get("ep_score", 0.0) for i in infos]))
 
+    @torch.no_grad()
+    def detached_batch_forward(self, obs, aux_features=None, max_batch_size=None, **kwargs):
+        """Forward a large batch in chunks, results concatenated (rl/rollout.py:557-598)."""
+        max_batch_size = max_batch_size or args.max_micro_batch_size
+        obs = self.model.prep_for_model(obs)
+        chunks = []
+        for i in range(0, obs.shape[0], max_batch_size):
+            out = self.model.forward(obs[i:i + max_batch_size], **kwargs)
+            chunks.append({k: v.clone() for k, v in out.items()})
+        return {k: torch.cat([c[k] for c in chunks], dim=0) for k in chunks[0]}
+
     # ------------------------------------------------------------------ returns
     def calculate_returns(self):
         """Advantages (lambda_policy) and value targets (lambda_value) in one fused scan
-        (rl/rollout.py:1182-1285 -> rl/returns.py:7-67)."""
+        (rl/rollout.py:1182-1285 -> rl/returns.py:7-67), then the TVF return targets (rl/tvf.py:210-271)."""
         N, A = self.N, self.A
-        assert self.VH == 1, "one extrinsic value head on this path"
-        value = self.value.view(N + 1, A)
+        if self.tvf is not None:
+            self._ext_estimate.copy_(self.tvf.get_tvf_ext_value_estimate(new_gamma=args.gamma))
+            value = self._ext_estimate
+        else:
+            value = self.value.view(N + 1, A)
         self._call("ppo_gae_scan_f32", _p(self.ext_rewards), _p(value), _p(value[N]), _p(self.terminals),
                    _lib.PPO_TERM_U8, _p(self.advantage), _p(self.returns), N, A, A, float(args.gamma),
                    float(args.lambda_policy), float(args.lambda_value), _lib.PPO_SCAN_AUTO)
+        if self.tvf is not None:
+            self.tvf.tvf_returns[..., 0].copy_(self.tvf.calculate_tvf_returns(value_head="ext"))
 
     # ------------------------------------------------------------------ training
     def _normalize_advantages(self):
@@ -234,65 +338,244 @@ class Runner:
         parallel.allreduce_sum_(self._moments)
         self._call("ppo_normalize_f32", _p(self.advantage), n, _p(self._moments), float(args.advantage_epsilon),
                    _p(self.norm_advantage), _p(self._mean_std))
+        if args.advantage_clipping is not None:
+            self.norm_advantage.clamp_(-args.advantage_clipping, args.advantage_clipping)
 
-    def optimizer_step(self, label="policy"):
+    def optimizer_step(self, optimizer=None, label="policy"):
         """All-reduce (DP) + global-norm clip + Adam in the flat buffer (rl/rollout.py:1287-1321)."""
-        net, cfg = self.net, args.policy_opt
+        opt = optimizer or self.policy_optimizer
+        net, cfg = opt.net, opt.cfg
         parallel.allreduce_sum_(net.grad)
         net.adam_step(lr=cfg.lr, beta1=cfg.adam_beta1, beta2=cfg.adam_beta2, eps=cfg.adam_epsilon,
                       max_grad_norm=args.max_grad_norm if args.grad_clip_mode == "global_norm" else 0.0,
-                      grad_div=float(self.world), grad_norm_out=self._grad_norm)
+                      grad_div=float(self.world), grad_norm_out=self._grad_norm, state=opt.state)
+        return self._grad_norm
 
-    def train_policy(self):
-        """PPO epochs over the rollout (rl/rollout.py:1853-1953, 2257-2407)."""
-        N, A = self.N, self.A
-        B = N * A
-        net = self.net
-        cfg = args.policy_opt
-        mb = parallel.local_minibatch(cfg.mini_batch_size)  # the flag is the GLOBAL minibatch (SURVEY.md §8e)
+    def _run_epochs(self, label, optimizer, epochs, mini_batch_size, step_fn, n_stats):
+        """Permutation minibatching over the rollout (rl/rollout.py:2257-2407): per epoch one host shuffle
+        (np.random, as the reference :2319-2320); per minibatch gather the observations, run
+        step_fn(mb_obs, index) -> per-sample stats [mb, n_stats], step the optimiser; the stats are column-
+        summed into one device row per minibatch."""
+        B = self.N * self.A
+        net = optimizer.net
+        mb = parallel.local_minibatch(mini_batch_size)  # the flag is the GLOBAL minibatch (SURVEY.md §8e)
         if B % mb:
             raise ValueError(f"batch {B} is not a multiple of the per-rank minibatch {mb}")
         n_mb = B // mb
-        self._normalize_advantages()
-        obs_rows = self.all_obs[:N].view(B, -1)
+        obs_rows = self.all_obs[:self.N].view(B, -1)
         row_bytes = obs_rows.shape[1] * obs_rows.element_size()
         mb_obs = net._buf("mb_obs", (mb, *self.state_shape), self.all_obs.dtype)
-        stat_rows = net._buf("stat_rows", (cfg.epochs * n_mb, 8))
-        norm_rows = net._buf("norm_rows", (cfg.epochs * n_mb,))
+        stat_rows = net._buf(f"stat_rows_{label}", (epochs * n_mb, n_stats))
+        norm_rows = net._buf(f"norm_rows_{label}", (epochs * n_mb,))
         k = 0
-        for epoch in range(cfg.epochs):
+        for _epoch in range(epochs):
             ordering = np.arange(B, dtype=np.int32)
-            np.random.shuffle(ordering)  # host RNG, as the reference (rl/rollout.py:2319-2320)
+            np.random.shuffle(ordering)
             order_dev = torch.from_numpy(ordering).to(self.device, non_blocking=True)
             for j in range(n_mb):
                 idx = order_dev[j * mb:(j + 1) * mb]
                 self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), mb, _p(mb_obs))
-                stats = net.ppo_minibatch(mb_obs, self.actions, self.log_pac, self.log_policy, self.norm_advantage,
-                                          self.returns, eps_clip=self.ppo_epsilon, ent_coef=self.current_entropy_bonus,
-                                          vf_coef=args.ppo_vf_coef, loss_scale=1.0, index=idx)
-                self.optimizer_step()
-                # keep the minibatch statistics on the device: column sums -> one row per minibatch
-                self._call("ppo_colsum_f32", _p(stats), mb, 8, 8, _p(stat_rows[k]), 0)
+                stats = step_fn(mb_obs, idx)
+                self.optimizer_step(optimizer, label)
+                self._call("ppo_colsum_f32", _p(stats), mb, n_stats, n_stats, _p(stat_rows[k]), 0)
                 norm_rows[k:k + 1].copy_(self._grad_norm, non_blocking=True)
                 k += 1
-        self._stat_rows = (stat_rows, norm_rows, mb)
+        self._phase_stats[label] = (stat_rows, norm_rows, mb)
+
+    def train_policy(self):
+        """PPO epochs over the rollout (rl/rollout.py:1853-1953); the single architecture trains the value
+        head in the same pass (:1744-1746)."""
+        if args.policy_opt.epochs == 0:
+            return
+        B = self.N * self.A
+        net = self.policy_net
+        self._normalize_advantages()
+        returns = None if self.dual else self.returns
+        net.zero_untouched_grads()
+        if self.action_dist == "discrete":
+            def step(mb_obs, idx):
+                return net.ppo_minibatch(mb_obs, self.actions, self.log_pac, self.log_policy, self.norm_advantage,
+                                         returns, eps_clip=self.ppo_epsilon, ent_coef=self.current_entropy_bonus,
+                                         vf_coef=args.ppo_vf_coef, loss_scale=1.0, index=idx)
+        else:
+            actions, log_pac = self.actions.view(B, self.n_actions), self.log_pac.view(B, self.n_actions)
+
+            def step(mb_obs, idx):
+                return net.gaussian_minibatch(mb_obs, actions, log_pac, self.norm_advantage, returns,
+                                              eps_clip=self.ppo_epsilon, vf_coef=args.ppo_vf_coef, loss_scale=1.0,
+                                              index=idx)
+        self._run_epochs("policy", self.policy_optimizer, args.policy_opt.epochs, args.policy_opt.mini_batch_size,
+                         step, 8)
+
+    def train_value(self):
+        """Value phase of the dual architecture (rl/rollout.py:1956-2004): value_net regresses the value
+        targets, and the TVF heads their truncated-return targets."""
+        if args.value_opt.epochs == 0:
+            return
+        B = self.N * self.A
+        net = self.value_net
+        use_ext = self.tvf is None or args.tvf.include_ext
+        returns = self.returns.view(B, self.VH) if use_ext else None
+        tvf_returns = self.tvf.tvf_returns[:, :, :, -1].reshape(B, self.K) if self.tvf is not None else None
+        weights = self._tvf_weights_dev if self.tvf is not None else None
+        net.zero_untouched_grads()
+
+        def step(mb_obs, idx):
+            return net.value_minibatch(mb_obs, returns=returns, tvf_returns=tvf_returns, tvf_weights=weights,
+                                       vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=1.0, index=idx)
+        self._run_epochs("value", self.value_optimizer, args.value_opt.epochs, args.value_opt.mini_batch_size, step, 4)
+
+    def wants_distil_update(self, location=None):
+        """rl/rollout.py:2211-2218."""
+        return (self.dual and args.distil_opt.epochs > 0 and self.step >= args.distil.delay * 1e6
+                and self.batch_counter % args.distil.period == args.distil.period - 1
+                and (location is None or location == args.distil.order))
+
+    def get_distil_batch(self, samples_wanted=None):
+        """Targets and the policy to stay close to, from the rollout (rl/rollout.py:2050-2112, the
+        replay-free path): value_net's estimates recorded during the rollout, and either the rollout's
+        policy (`before_policy`) or the just-updated policy re-evaluated over the batch (`after_policy`)."""
+        N, A = self.N, self.A
+        B = N * A
+        if samples_wanted not in (None, B) or (0 < args.distil.batch_size != B):
+            raise NotImplementedError("distillation from a replay buffer is out of scope; distil_batch_size = rollout")
+        if args.distil.target != "value" or args.distil.loss != "kl_policy" or args.distil.value_loss != "mse":
+            raise NotImplementedError("distil target 'value', loss 'kl_policy', value_loss 'mse' are built")
+        use_tvf = self.tvf is not None and not args.distil.force_ext
+        if use_tvf and 0 < args.distil.max_heads < self.K:
+            raise NotImplementedError("distil_max_heads sub-sampling is not built (default: all heads)")
+        batch = {"use_tvf": use_tvf}
+        if use_tvf:
+            batch["distil_targets"] = self.tvf.tvf_untrimmed_value[:N, :, :, 0].reshape(B, self.K)
+        else:
+            batch["distil_targets"] = self.value[:N].reshape(B)
+        key = "raw_policy" if self.action_dist == "gaussian" else "log_policy"
+        if args.distil.order == "before_policy":
+            old = getattr(self, key).view(B, self.n_actions)
+        else:
+            net = self.policy_net
+            old = net._buf("distil_old_policy", (B, self.n_actions))
+            obs = self.all_obs[:N].view(B, *self.state_shape)
+            chunk = max(args.max_micro_batch_size, 1)
+            for i in range(0, B, chunk):
+                out = net.forward(obs[i:i + chunk], exclude_value=True)
+                old[i:i + chunk].copy_(out[key])
+        batch["old_policy"] = old
+        return batch
+
+    def train_distil(self):
+        """Distillation phase (rl/rollout.py:2140-2164): policy_net's value (or TVF) heads learn value_net's
+        estimates under a KL constraint that keeps the policy where it is."""
+        if args.distil_opt.epochs == 0:
+            return
+        batch = self.get_distil_batch()
+        net = self.policy_net
+        gaussian = self.action_dist == "gaussian"
+        weights = self._tvf_weights_dev if batch["use_tvf"] else None
+        net.zero_untouched_grads()
+
+        def step(mb_obs, idx):
+            return net.distil_minibatch(mb_obs, batch["distil_targets"], batch["old_policy"], beta=args.distil.beta,
+                                        use_tvf=batch["use_tvf"], weights=weights, gaussian=gaussian, loss_scale=1.0,
+                                        index=idx)
+        opt = self.policy_optimizer if args.distil.use_policy_opt else self.distil_optimizer
+        self._run_epochs("distil", Optimizer(net, args.distil_opt, opt.state), args.distil_opt.epochs,
+                         args.distil_opt.mini_batch_size, step, 4)
 
     def train(self):
-        """rl/rollout.py:2220-2255 for the single architecture: policy (+value heads) only."""
+        """rl/rollout.py:2220-2255: [distil] -> policy -> (dual) value -> [distil]."""
+        self._phase_stats = {}
+        if self.wants_distil_update("before_policy"):
+            self.train_distil()
         self.train_policy()
+        if self.dual:
+            self.train_value()
+            if self.wants_distil_update("after_policy"):
+                self.train_distil()
         self.batch_counter += 1
 
+    # ---- the reference's dict-based minibatch API (rl/rollout.py:1331, 1513, 1610, 2257), for callers that
+    # drive the phases themselves; `data` holds minibatch-sized device tensors
+    def train_policy_minibatch(self, data, loss_scale=1.0):
+        net = self.policy_net
+        returns = data.get("returns") if not self.dual else None
+        if self.action_dist == "discrete":
+            stats = net.ppo_minibatch(data["prev_state"], data["actions"].to(torch.int32), data["log_pac"],
+                                      data.get("log_policy"), data["advantages"], returns, eps_clip=self.ppo_epsilon,
+                                      ent_coef=self.current_entropy_bonus, vf_coef=args.ppo_vf_coef,
+                                      loss_scale=loss_scale)
+        else:
+            stats = net.gaussian_minibatch(data["prev_state"], data["actions"], data["log_pac"], data["advantages"],
+                                           returns, eps_clip=self.ppo_epsilon, vf_coef=args.ppo_vf_coef,
+                                           loss_scale=loss_scale)
+        s = stats.double().mean(0).cpu().numpy()
+        return {"loss": float(-s[6] * loss_scale), "kl_approx": float(s[4]), "kl_true": float(s[5]), "clip_frac": float(s[3])}
+
+    def train_value_minibatch(self, data, loss_scale=1.0, single_value_head=None):
+        if single_value_head is not None:
+            raise NotImplementedError("training a single TVF head (noise-scale estimation) is out of scope")
+        weights = self._tvf_weights_dev if "tvf_returns" in data else None
+        stats = self.value_net.value_minibatch(data["prev_state"], returns=data.get("returns"),
+                                               tvf_returns=data.get("tvf_returns"), tvf_weights=weights,
+                                               vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=loss_scale)
+        total = stats[:, 2].double() * loss_scale
+        return {"loss": float(total.mean()), "loss_std": float(total.std())}
+
+    def train_distil_minibatch(self, data, loss_scale=1.0, **kwargs):
+        use_tvf = self.tvf is not None and not args.distil.force_ext
+        gaussian = self.action_dist == "gaussian"
+        stats = self.policy_net.distil_minibatch(
+            data["prev_state"], data["distil_targets"], data["old_raw_policy" if gaussian else "old_log_policy"],
+            beta=args.distil.beta, use_tvf=use_tvf, weights=self._tvf_weights_dev if use_tvf else None,
+            gaussian=gaussian, loss_scale=loss_scale)
+        total = stats[:, 2].double() * loss_scale
+        return {"loss": float(total.mean()), "loss_std": float(total.std())}
+
+    def train_batch(self, batch_data, mini_batch_func, mini_batch_size, optimizer, label, epoch=None, hooks=None,
+                    thinning=1.0, force_micro_batch_size=None, delta_threshold=None):
+        """One epoch of permutation minibatches through `mini_batch_func(data, loss_scale=...)`
+        (rl/rollout.py:2257-2407).  Micro-batch splitting is not needed with 288 GB of HBM: every minibatch
+        is one pass."""
+        assert "prev_state" in batch_data, "Batches must contain 'prev_state' field of dims (B, *state_shape)"
+        B = len(batch_data["prev_state"])
+        mb = parallel.local_minibatch(mini_batch_size)
+        ordering = np.arange(B)
+        np.random.shuffle(ordering)
+        n = int((B // mb) * thinning) or 1
+        counter, last = 0, None
+        data = {k: (torch.as_tensor(v).to(self.device)) for k, v in batch_data.items() if not k.startswith("*")}
+        for j in range(n):
+            idx = torch.from_numpy(ordering[j * mb:(j + 1) * mb]).to(self.device)
+            optimizer.zero_grad()
+            last = mini_batch_func({k: v[idx].contiguous() for k, v in data.items()}, loss_scale=1.0)
+            self.optimizer_step(optimizer, label)
+            counter += 1
+        out = dict(last or {})
+        out["mini_batches"] = counter
+        return out
+
     def fetch_stats(self):
-        """ONE device->host copy per iteration with everything the reference logs per minibatch
-        (rl/rollout.py:1685-1691, 1759-1769, 1317)."""
-        if self._stat_rows is None:
-            return {}
-        stat_rows, norm_rows, mb = self._stat_rows
-        s = stat_rows.cpu().numpy().astype(np.float64) / mb
-        out = {"loss_pg": s[:, 0].mean(), "entropy": s[:, 1].mean(), "loss_v_ext": s[:, 2].mean(),
-               "clip_frac": s[:, 3].mean(), "kl_approx": s[:, 4].mean(), "kl_true": s[:, 5].mean(),
-               "loss_policy": s[:, 6].mean(), "grad_policy": float(norm_rows.mean().item()),
-               "adv_mean": float(self._mean_std[0].item()), "adv_std": float(self._mean_std[1].item())}
+        """ONE device->host copy per phase and iteration with everything the reference logs per minibatch
+        (rl/rollout.py:1685-1691, 1759-1769, 1317, 1427-1446, 1563)."""
+        out = {}
+        if "policy" in self._phase_stats:
+            stat_rows, norm_rows, mb = self._phase_stats["policy"]
+            s = stat_rows.cpu().numpy().astype(np.float64) / mb
+            out.update({"loss_pg": s[:, 0].mean(), "entropy": s[:, 1].mean(), "loss_v_ext": s[:, 2].mean(),
+                        "clip_frac": s[:, 3].mean(), "kl_approx": s[:, 4].mean(), "kl_true": s[:, 5].mean(),
+                        "loss_policy": s[:, 6].mean(), "grad_policy": float(norm_rows.mean().item()),
+                        "adv_mean": float(self._mean_std[0].item()), "adv_std": float(self._mean_std[1].item())})
+        if "value" in self._phase_stats:
+            stat_rows, norm_rows, mb = self._phase_stats["value"]
+            s = stat_rows.cpu().numpy().astype(np.float64) / mb
+            out.update({"loss_v_ext": s[:, 0].mean(), "loss_tvf": s[:, 1].mean(), "loss_value": s[:, 2].mean(),
+                        "grad_value": float(norm_rows.mean().item())})
+        if "distil" in self._phase_stats:
+            stat_rows, norm_rows, mb = self._phase_stats["distil"]
+            s = stat_rows.cpu().numpy().astype(np.float64) / mb
+            out.update({"loss_distil_value": s[:, 0].mean(), "loss_distil_policy": s[:, 1].mean(),
+                        "loss_distil": s[:, 2].mean(), "distil_mse": s[:, 3].mean(),
+                        "grad_distil": float(norm_rows.mean().item())})
         if not args.disable_logging:
             for k_, v in out.items():
                 self.log.watch_mean(k_, v)
@@ -302,14 +585,20 @@ class Runner:
     def save_checkpoint(self, filename, step, disable_log=False, disable_replay=False, disable_env_state=False):
         data = {"step": step, "ep_count": self.ep_count, "batch_counter": self.batch_counter,
                 "model_state_dict": self.model.state_dict(),
-                "policy_optimizer_state_dict": self.net.optimizer_state_dict()}
+                "policy_optimizer_state_dict": self.policy_optimizer.state_dict()}
+        if self.dual:
+            data["value_optimizer_state_dict"] = self.value_optimizer.state_dict()
+            data["distil_optimizer_state_dict"] = self.distil_optimizer.state_dict()
         torch.save(data, filename)
 
     def load_checkpoint(self, checkpoint_path):
         cp = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         self.model.load_state_dict(cp["model_state_dict"])
-        if "policy_optimizer_state_dict" in cp:
-            self.net.load_optimizer_state_dict(cp["policy_optimizer_state_dict"])
+        for key, opt in (("policy_optimizer_state_dict", self.policy_optimizer),
+                         ("value_optimizer_state_dict", self.value_optimizer if self.dual else None),
+                         ("distil_optimizer_state_dict", self.distil_optimizer)):
+            if opt is not None and key in cp:
+                opt.load_state_dict(cp[key])
         self.step = cp["step"]
         self.ep_count = cp.get("ep_count", 0)
         self.batch_counter = cp.get("batch_counter", 0)

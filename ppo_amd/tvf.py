@@ -57,3 +57,73 @@ def horizon_interpolate(horizons: np.ndarray, values: np.ndarray, target_horizon
     result = flat_v[rows, lo] * (1 - frac) + flat_v[rows, hi] * frac
     result[hi == 0] = 0
     return result.reshape(shape)
+
+
+def get_rediscounted_value_estimate(values, old_gamma: float, new_gamma: float, horizons, clipping=10):
+    """Re-discount per-horizon values [B, K] from old_gamma to new_gamma (rl/tvf.py:388-433): the reward mass
+    between consecutive horizons is re-weighted by (new/old)^mid_h, ratio clipped; equal gammas return the
+    longest horizon.  NumPy in -> NumPy out, tensor in -> tensor out (tiny: setup-time / rare, R8)."""
+    import torch
+    B, K = values.shape
+    if old_gamma == new_gamma:
+        return values[:, -1]
+    assert K == len(horizons), f"missmatch {K} {horizons}"
+    assert horizons[0] == 0, "first horizon must be 0"
+    is_numpy = isinstance(values, np.ndarray)
+    v = torch.from_numpy(values) if is_numpy else values
+    total = torch.zeros([B], dtype=torch.float32, device=v.device)
+    prev, prev_h = v[:, 0], 0
+    for i, h in enumerate(horizons[1:], start=1):
+        mid_h = ((prev_h + 1 + h) / 2) - 1
+        ratio = min((new_gamma ** mid_h) / (old_gamma ** mid_h), clipping)
+        total += (v[:, i] - prev) * ratio
+        prev, prev_h = v[:, i], h
+    return total.numpy() if is_numpy else total
+
+
+class TVFRunnerModule:
+    """Rollout-side TVF state (rl/tvf.py:18-386) with the buffers in HBM: per-horizon value estimates
+    `tvf_value [N+1, A, K, VH]` written by the rollout's policy step and `tvf_returns [N, A, K, VH]` filled
+    by calculate_tvf_returns from the HIP truncated-returns kernel.  Horizon trimming (off by default,
+    rl/config.py:217) is not built, so trimmed == untrimmed values."""
+
+    def __init__(self, parent):
+        import torch
+        from .config import args
+        if args.tvf.trimming != "off" or args.tvf.head_weighting != "off" or args.tvf.horizon_dropout > 0:
+            raise NotImplementedError("TVF trimming / head weighting / horizon dropout are off by default and not built")
+        self.runner = parent
+        N, A, K, VH = parent.N, parent.A, len(parent.tvf_horizons), parent.VH
+        dev = parent.device
+        self.tvf_value = torch.zeros((N + 1, A, K, VH), dtype=torch.float32, device=dev)
+        self.tvf_untrimmed_value = self.tvf_value
+        self.tvf_returns = torch.zeros((N, A, K, VH), dtype=torch.float32, device=dev)
+
+    def calculate_tvf_returns(self, value_head: str = "ext", obs=None, rewards=None, dones=None, tvf_return_mode=None,
+                              tvf_return_distribution=None, tvf_n_step=None):
+        """[N, A, K] truncated return estimates for the rollout (rl/tvf.py:210-271)."""
+        from .config import args
+        r = self.runner
+        horizons = np.asarray(r.tvf_horizons)
+        values = self.tvf_value[..., r.value_heads.index(value_head)]
+        return get_return_estimate(
+            mode=tvf_return_mode or args.tvf.return_mode,
+            distribution=tvf_return_distribution or args.tvf.return_distribution,
+            gamma=args.tvf.gamma,
+            rewards=rewards if rewards is not None else r.ext_rewards,
+            dones=dones if dones is not None else r.terminals,
+            required_horizons=horizons, value_sample_horizons=horizons, value_samples=values.contiguous(),
+            n_step=tvf_n_step or args.tvf_return_n_step, max_samples=args.tvf.return_samples,
+            use_log_interpolation=args.tvf.return_use_log_interpolation)
+
+    def get_tvf_ext_value_estimate(self, new_gamma: float):
+        """[N+1, A] value estimate for GAE: the longest horizon (rl/tvf.py:304-338), re-discounted when the
+        policy gamma differs from the TVF gamma (:353-360)."""
+        from .config import args
+        r = self.runner
+        v = self.tvf_value[:, :, :, r.value_heads.index("ext")]
+        if abs(new_gamma - args.tvf.gamma) < 1e-8:
+            return v[:, :, -1]
+        N1, A, K = v.shape
+        return get_rediscounted_value_estimate(v.reshape(N1 * A, K), args.tvf.gamma, new_gamma,
+                                               r.tvf_horizons).reshape(N1, A)

@@ -34,3 +34,24 @@ def test_geometry():
     spec = ImpalaSpec((4, 84, 84))
     assert spec.out_shape == (32, 11, 11) and spec.flat == 3872
     assert ImpalaSpec((3, 64, 64)).flat == 32 * 8 * 8
+
+
+def test_mlp_dual_tvf_initial_parameters_match_reference_bitwise(golden_dir):
+    """MLP encoder, dual architecture (policy_net then value_net drawn in sequence), with and without the
+    TVF head (tests/golden/make_variants_golden.py; rl/models.py:157-161, 364-384, 605-607)."""
+    from ppo_amd.models import MLPSpec, init_parameters
+    meta = json.load(open(os.path.join(golden_dir, "variants_golden.json")))
+    gold = np.load(os.path.join(golden_dir, "variants_golden.npz"))
+    for tag in ("mlp_gauss_tvf", "mlp_disc"):
+        m = meta[tag]
+        n_tvf = len(gold[f"{tag}_tvf_horizons"]) if f"{tag}_tvf_horizons" in gold else 0
+        torch.manual_seed(7)
+        spec = MLPSpec(tuple(m["input_dims"]), hidden_units=m["hidden"])
+        for prefix in ("policy_net", "value_net"):
+            init = init_parameters(spec, m["n_actions"], 1, m["head_scale"], m["head_bias"], n_tvf)
+            want = {k[len(prefix) + 1:]: v for k, v in m["params"].items() if k.startswith(prefix + ".")}
+            assert set(init) == set(want), (tag, prefix)
+            for name, info in want.items():
+                a = np.ascontiguousarray(init[name].numpy())
+                assert list(a.shape) == info["shape"], name
+                assert hashlib.sha256(a.tobytes()).hexdigest() == info["sha256"], (tag, prefix, name)

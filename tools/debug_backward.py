@@ -29,7 +29,7 @@ def fwd(x):
     return o
 o = fwd(x.to(dt) / 255.0)
 acts = net.encode(x, train=True)
-oh = net.heads(acts["h"], "t")
+oh = net.heads(acts, "t")
 print("fwd heads err", (oh.double() - o).abs().max().item() / o.abs().max().item())
 for k in ["c0", "p0", "a0_0", "q0_1", "c1", "q1_1", "c2", "q2_1"]:
     pass

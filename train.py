@@ -22,11 +22,19 @@ from ppo_amd.config import args  # noqa: E402
 
 def make_model(log):
     """train.py:33-82 of the reference: model from the env's spaces and the model flags."""
+    from ppo_amd import tvf
     obs_shape, n_actions = envs.get_env_spec()
+    horizons = weights = None
+    if args.tvf.enabled:
+        horizons, weights = tvf.get_value_head_horizons(args.tvf.value_heads, args.tvf.max_horizon,
+                                                        args.tvf.head_spacing, include_weight=True)
+        args.tvf.value_heads = len(horizons)  # duplicate horizons are merged (train.py:50-52)
     return models.TVFModel(
         encoder=args.model.encoder, encoder_args=args.model.encoder_args, input_dims=obs_shape, actions=n_actions,
         device=args.device, architecture=args.model.architecture, dtype=torch.float32,
-        hidden_units=args.model.hidden_units, encoder_activation_fn="relu", head_scale=args.model.head_scale,
+        hidden_units=args.model.hidden_units,
+        encoder_activation_fn="tanh" if args.env.type == "mujoco" else "relu",
+        tvf_fixed_head_horizons=horizons, tvf_fixed_head_weights=weights, head_scale=args.model.head_scale,
         head_bias=args.model.head_bias, value_head_names=("ext",))
 
 
