@@ -12,10 +12,13 @@
 //
 // Mapping: a 512-thread workgroup (8 waves) walks (image, band of TR output rows) items for all
 // output channels.  The input band (+1-pixel halo, zero padded) sits in LDS as planar
-// [ci][row][col] (plane stride = 16 mod 32 banks); the weights sit in LDS as [k/2][co][2] with
-// k = tap*CINP + ci.  GEMM view: M = output channel (MFMA "i"), N = pixel (MFMA "j"), K = 9*CIN.
-// A wave holds MT pixel tiles x NT channel tiles of 16x16 accumulators; every operand read is a
-// ds_read_b32 at an immediate offset from a per-lane base, software-pipelined two K steps ahead.
+// [ci][row][col] (plane stride = 16 mod 32 banks); the weights live in REGISTERS for the whole
+// kernel (each lane's A-operand slice wa[NT][K/4], loaded once: the filter bank is at most 36 KB and
+// every wave needs all of it for every item), as does the bias.  GEMM view: M = output channel
+// (MFMA "i"), N = pixel (MFMA "j"), K = 9*CIN with k = tap*CINP + ci.
+// A wave holds MT pixel tiles x NT channel tiles of 16x16 accumulators; every activation read is a
+// ds_read_b32 at an immediate offset from a per-lane base, software-pipelined two K steps ahead
+// (hand-unrolled, sched_barrier-fenced); output stores are deferred into the next item's K loop.
 //
 // Pipeline (float inputs): the band is DOUBLE-BUFFERED and filled by LDS-DMA (global_load_lds): the
 // next item's band is requested right after the barrier that publishes the current one, so HBM latency,

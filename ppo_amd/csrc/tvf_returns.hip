@@ -49,11 +49,8 @@ __global__ __launch_bounds__(256) void tvf_prefix_kernel(const float *__restrict
     }
 }
 
-struct Plan {  // how to evaluate interp(values[..., :], target): mode 0 zero, 1 values[i0], 2 v[i0]*w0 + v[i1]*w1
-    int mode, i0, i1;
-    float w0, w1;
-};
-
+// A plan row (mode, i0, i1) + weights (w0, w1) says how to evaluate interp(values[..., :], target):
+// mode 0 -> zero, 1 -> values[i0], 2 -> values[i0]*w0 + values[i1]*w1.
 // The two-column case is evaluated in float64 and rounded once: in the reference the interpolation factor
 // is a NumPy float64 scalar (a quotient of NumPy integers), and under NumPy >= 2 promotion (NEP 50, the NumPy
 // the golden vectors were produced with) float32_array * float64_scalar is a float64 array; the float32

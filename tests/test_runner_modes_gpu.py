@@ -88,9 +88,9 @@ def test_dual_architecture_runs_policy_value_distil_phases():
     for k in ("loss_pg", "loss_value", "loss_distil", "loss_distil_policy", "grad_value", "grad_distil"):
         assert np.isfinite(stats[k]), k
     assert stats["loss_v_ext"] > 0 and stats["loss_distil_value"] > 0
-    # the distil phase starts at the policy it must stay close to: first minibatch KL is exactly 0
+    # the distil phase starts at the policy it must stay close to: first minibatch KL is 0 to rounding
     first = float(r._phase_stats["distil"][0][0, 1].item())
-    assert first == 0.0 and stats["loss_distil_policy"] < 1e-3
+    assert abs(first) < 1e-5 and stats["loss_distil_policy"] < 1e-3
     assert r.batch_counter == 1 and r.wants_distil_update("after_policy") and not r.wants_distil_update("before_policy")
     # second iteration
     r.generate_rollout()
