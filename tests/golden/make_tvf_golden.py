@@ -101,6 +101,14 @@ def main():
         for sp in ("geometric", "linear"):
             h, wts = tvf.get_value_head_horizons(nh, mh, sp, include_weight=True)
             out[f"vh_{nh}_{mh}_{sp}_h"], out[f"vh_{nh}_{mh}_{sp}_w"] = np.asarray(h), np.asarray(wts)
+    # get_rediscounted_value_estimate (rl/tvf.py:388-433): cumulative per-horizon values, three gamma pairs
+    rng_rd = np.random.default_rng(77)
+    hz_rd = np.asarray(tvf.get_value_head_horizons(16, 3000, "geometric"))
+    v_rd = np.cumsum(rng_rd.random((12, len(hz_rd))).astype(np.float32), axis=1)
+    v_rd[:, 0] = 0
+    out["rd_horizons"], out["rd_values"] = hz_rd, v_rd
+    for tag, (g_old, g_new) in {"same": (0.999, 0.999), "down": (0.9999, 0.99), "up": (0.99, 0.9999)}.items():
+        out[f"rd_{tag}"] = np.asarray(tvf.get_rediscounted_value_estimate(v_rd, g_old, g_new, hz_rd))
     np.savez_compressed(os.path.join(HERE, "tvf_golden.npz"), **out)
     json.dump(meta, open(os.path.join(HERE, "tvf_golden.json"), "w"), indent=1)
     print("wrote", len(out), "arrays", sum(x.nbytes for x in out.values()) / 1e6, "MB raw")

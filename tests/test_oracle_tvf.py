@@ -66,6 +66,18 @@ def test_horizon_helpers_oracle_and_product(gold):
             mod.get_value_head_horizons(8, 100, "banana")
 
 
+def test_rediscounted_value_estimate_matches_reference(gold):
+    """rl/tvf.py:388-433: equal gammas return the longest horizon; otherwise the per-interval reward mass is
+    re-weighted by the (clipped) discount ratio.  Product (host-side, R8) against the reference's outputs."""
+    g, _ = gold
+    from ppo_amd import tvf as P
+    for tag, (g_old, g_new) in {"same": (0.999, 0.999), "down": (0.9999, 0.99), "up": (0.99, 0.9999)}.items():
+        got = P.get_rediscounted_value_estimate(g["rd_values"], g_old, g_new, g["rd_horizons"])
+        assert got.dtype == g[f"rd_{tag}"].dtype and np.array_equal(got, g[f"rd_{tag}"]), tag
+    assert np.array_equal(g["rd_same"], g["rd_values"][:, -1])
+    assert (g["rd_down"] < g["rd_same"]).all() and (g["rd_up"] > g["rd_same"]).all()
+
+
 def test_product_interpolation_plan_matches_oracle():
     from ppo_amd.returns_truncated import interpolation_plan as plan
     hz = np.asarray([0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64])
