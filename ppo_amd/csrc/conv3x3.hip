@@ -32,8 +32,11 @@
 namespace ppo {
 namespace {
 
-constexpr int kConvWaves = 8;
-constexpr int kConvThreads = kConvWaves * 64;
+// Waves per workgroup (NW) is a per-geometry choice: 8 for the 16-channel layers (several workgroups fit a
+// CU), 4 for the 32-channel layers, whose 144 weight registers per lane allow only 8 waves per CU in total:
+// two independent 4-wave workgroups then interleave their barrier / epilogue phases with each other's K
+// loops, where one 8-wave workgroup leaves the MFMA pipe idle while all its waves sit in the same phase
+// (stamps build: 29 % of an item outside the K loop).
 
 // Diagnostic build only (tools/conv_tune -DPPO_TUNE_STAMPS): s_memtime stamps around the phases of an
 // item, summed per phase over all waves into a buffer nothing else reads (cdna_hip_programming.md §7).
@@ -56,9 +59,9 @@ struct ConvCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;  // k-steps of 4 channels
     static constexpr int COUTP = (COUT + 15) / 16 * 16;
     static constexpr int NT = COUTP / 16;
-    static constexpr int PW = W + 2;
-    static constexpr int ROWS = TR + 2;
-    static constexpr int PLANE_RAW = ROWS * PW;
+    static constexpr int ROWS = TR + 2;             // one halo row above and below; no halo columns
+    static constexpr int G = 4;                     // guard floats around the rows of a plane
+    static constexpr int PLANE_RAW = ROWS * W + 2 * G;
     static constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;  // = 16 (mod 32)
     static constexpr int K = 9 * CINP;
     static constexpr int NBANDS = (H + TR - 1) / TR;
@@ -69,13 +72,14 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(NBUF * LDS_IN) * 4;
 };
 
-template <int CIN, int COUT, int H, int W, int TR, int MT, int IN_MODE, bool TRANSPOSED>
-__global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED>
+__global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     const void *__restrict__ in_, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ residual, const float *__restrict__ mask_src, float *__restrict__ out,
     int n_images)
 {
     constexpr bool DMA = IN_MODE != IN_U8;
+    constexpr int kConvWaves = NW, kConvThreads = NW * 64;
     using C = ConvCfg<CIN, COUT, H, W, TR, DMA>;
     extern __shared__ __align__(16) float smem[];
 
@@ -124,9 +128,9 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
         if constexpr (DMA)
-            stage_band_dma<CIN, H, W, C::ROWS, C::PW, C::PLANE, 1, kConvWaves>(static_cast<const float *>(in_), img, y0, dst, tid);
+            stage_band_chunk_dma<CIN, H, W, C::ROWS, C::PLANE, C::G, kConvWaves>(static_cast<const float *>(in_), img, y0, dst, tid);
         else
-            stage_band<CIN, C::CINP, H, W, C::ROWS, C::PW, C::PLANE, 1, IN_MODE, kConvWaves>(in_, img, y0, dst, tid);
+            stage_band_flat<CIN, C::CINP, H, W, C::ROWS, C::PLANE, C::G, IN_MODE, kConvWaves>(in_, img, y0, dst, tid);
     };
     if (DMA && (int)blockIdx.x < n_items) stage(blockIdx.x, smem);
 
@@ -135,6 +139,11 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
     constexpr int NGW = (GROUPS + kConvWaves - 1) / kConvWaves;  // group slots per wave
     int pix[NGW][MT];   // pixel index inside the band = its offset inside a channel plane of the band
     int lofs[NGW][MT];  // LDS offset of the pixel's 3x3 window origin (+ this lane group's channel plane)
+    // The band has no halo columns: at the image's left (right) edge the x-1 (x+1) taps read a neighbouring
+    // row's pixel and are forced to 0 instead.  hi_l / hi_r are the upper clamp of a med3(v, lo, hi): 0 for
+    // an edge pixel, +inf otherwise; with lo = 0 the same instruction is also the ReLU-on-read, with
+    // lo = -hi it only masks (clamp to [0, 0] or to [-inf, +inf]).
+    float hi_l[NGW][MT], hi_r[NGW][MT];
 #pragma unroll
     for (int q = 0; q < NGW; ++q)
 #pragma unroll
@@ -142,7 +151,9 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
             const int p = ((wave + q * kConvWaves) * MT + m) * 16 + l15;
             pix[q][m] = p;
             const int pc = p < C::NPIX ? p : 0;
-            lofs[q][m] = (pc / W) * C::PW + (pc % W) + g * C::PLANE;
+            lofs[q][m] = C::G + pc - 1 + g * C::PLANE;  // window origin = (row, x - 1); rows are W apart
+            hi_l[q][m] = (pc % W == 0) ? 0.f : INFINITY;
+            hi_r[q][m] = (pc % W == W - 1) ? 0.f : INFINITY;
         }
 
     // results of the last group a wave computed are STORED one barrier later (after the next item's
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
             auto load_step = [&](int s, float (&bb)[MT]) {
                 const int tap = s / (C::CINP / 4);
                 const int cs = s % (C::CINP / 4);
-                const int tap_off = (tap / 3) * C::PW + (tap % 3);
+                const int tap_off = (tap / 3) * W + (tap % 3);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) bb[m] = smem[base[m] + cs * 4 * C::PLANE + tap_off];
             };
@@ -256,7 +267,14 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     float bv = b[s % (PF + 1)][m];
-                    if (IN_MODE == IN_RELU) bv = relu1(bv);  // pre-activation input: ReLU on read
+                    // one med3 per operand: ReLU on read (pre-activation input) and/or the edge mask
+                    const int kx = (s / (C::CINP / 4)) % 3;
+                    if (kx != 1) {
+                        const float hi = kx == 0 ? hi_l[q][m] : hi_r[q][m];
+                        bv = __builtin_amdgcn_fmed3f(bv, IN_MODE == IN_RELU ? 0.f : -hi, hi);
+                    } else if (IN_MODE == IN_RELU) {
+                        bv = relu1(bv);
+                    }
 #pragma unroll
                     for (int n = 0; n < C::NT; ++n) acc[n][m] = mfma16(wa[n][s], bv, acc[n][m]);
                 }
@@ -291,12 +309,13 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_kernel(
     flush();
 }
 
-template <int CIN, int COUT, int H, int W, int TR, int MT, int IN_MODE, bool TRANSPOSED>
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED>
 int launch_conv(const void *in, const float *w, const float *bias, const float *residual,
                 const float *mask_src, float *out, int n_images, hipStream_t st)
 {
     using C = ConvCfg<CIN, COUT, H, W, TR, IN_MODE != IN_U8>;
-    auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, IN_MODE, TRANSPOSED>;
+    auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED>;
+    constexpr int kConvThreads = NW * 64;
     static int wg_per_cu = 0;  // resident workgroups per CU (LDS- and VGPR-limited), queried once
     if (wg_per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -305,7 +324,10 @@ int launch_conv(const void *in, const float *w, const float *bias, const float *
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kConvThreads, C::LDS_BYTES);
         if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3: occupancy query: %s", hipGetErrorString(e));
-        wg_per_cu = nb < 1 ? 1 : (nb > 3 ? 3 : nb);
+        wg_per_cu = nb < 1 ? 1 : (nb > 24 / NW ? 24 / NW : nb);
+#ifdef PPO_TUNE_WG_PER_CU  // tools/conv_tune experiment build only
+        wg_per_cu = PPO_TUNE_WG_PER_CU < wg_per_cu ? PPO_TUNE_WG_PER_CU : wg_per_cu;
+#endif
     }
     const int n_items = n_images * C::NBANDS;
     int grid = 256 * wg_per_cu;
@@ -324,30 +346,33 @@ int dispatch_conv(int cin, int cout, int h, int w_, const void *in, const float 
 {
 // FIRST: the obs conv (uint8 or float obs, never ReLU-on-load, never transposed);
 // UP: the channel-changing stack-first conv; SAME: everything else.
-#define PPO_CONV_CASE(ALLOWED, CI, CO, HH, WW, TR, MT)                                             \
-    if constexpr (ALLOWED) {                                                                       \
-        if (cin == CI && cout == CO && h == HH && w_ == WW)                                        \
-            return launch_conv<CI, CO, HH, WW, TR, MT, IN_MODE, TRANSPOSED>(in, w, bias, residual, \
-                                                                             mask_src, out, n, st); \
+#define PPO_CONV_CASE(ALLOWED, CI, CO, HH, WW, TR, MT, NW)                                              \
+    if constexpr (ALLOWED) {                                                                           \
+        if (cin == CI && cout == CO && h == HH && w_ == WW)                                            \
+            return launch_conv<CI, CO, HH, WW, TR, MT, NW, IN_MODE, TRANSPOSED>(in, w, bias, residual, \
+                                                                                 mask_src, out, n, st); \
     }
+#ifndef PPO_NW32
+#define PPO_NW32 4
+#endif
     constexpr bool FIRST = !TRANSPOSED && IN_MODE != IN_RELU;
     constexpr bool UP = !TRANSPOSED && IN_MODE == IN_NONE;
     constexpr bool DOWN = TRANSPOSED;
     constexpr bool SAME = IN_MODE != IN_U8;
-    PPO_CONV_CASE(FIRST, 4, 16, 84, 84, 12, 4)   // 63 tiles -> 16 groups of 4: 2 per wave
-    PPO_CONV_CASE(FIRST, 5, 16, 84, 84, 12, 4)
-    PPO_CONV_CASE(FIRST, 3, 16, 64, 64, 16, 4)   // 64 tiles -> 16 groups
-    PPO_CONV_CASE(FIRST, 4, 16, 64, 64, 16, 4)
-    PPO_CONV_CASE(UP, 16, 32, 42, 42, 6, 2)      // 252 px = 16 tiles -> 8 groups of 2: 1 per wave
-    PPO_CONV_CASE(UP, 16, 32, 32, 32, 8, 2)      // 256 px = 16 tiles
-    PPO_CONV_CASE(DOWN, 32, 16, 42, 42, 6, 2)
-    PPO_CONV_CASE(DOWN, 32, 16, 32, 32, 8, 2)
-    PPO_CONV_CASE(SAME, 16, 16, 42, 42, 6, 2)
-    PPO_CONV_CASE(SAME, 16, 16, 32, 32, 8, 2)
-    PPO_CONV_CASE(SAME, 32, 32, 21, 21, 6, 1)    // 126 px = 8 tiles: 1 per wave
-    PPO_CONV_CASE(SAME, 32, 32, 16, 16, 8, 1)    // 128 px = 8 tiles
-    PPO_CONV_CASE(SAME, 32, 32, 11, 11, 11, 1)   // 121 px = 8 tiles
-    PPO_CONV_CASE(SAME, 32, 32, 8, 8, 8, 1)      // 64 px = 4 tiles (half the waves idle: tiny layer)
+    PPO_CONV_CASE(FIRST, 4, 16, 84, 84, 12, 4, 8)   // 63 tiles -> 16 groups of 4: 2 per wave
+    PPO_CONV_CASE(FIRST, 5, 16, 84, 84, 12, 4, 8)
+    PPO_CONV_CASE(FIRST, 3, 16, 64, 64, 16, 4, 8)   // 64 tiles -> 16 groups
+    PPO_CONV_CASE(FIRST, 4, 16, 64, 64, 16, 4, 8)
+    PPO_CONV_CASE(UP, 16, 32, 42, 42, 6, 2, 8)      // 252 px = 16 tiles -> 8 groups of 2: 1 per wave
+    PPO_CONV_CASE(UP, 16, 32, 32, 32, 8, 2, 8)      // 256 px = 16 tiles
+    PPO_CONV_CASE(DOWN, 32, 16, 42, 42, 6, 2, 8)
+    PPO_CONV_CASE(DOWN, 32, 16, 32, 32, 8, 2, 8)
+    PPO_CONV_CASE(SAME, 16, 16, 42, 42, 6, 2, 8)
+    PPO_CONV_CASE(SAME, 16, 16, 32, 32, 8, 2, 8)
+    PPO_CONV_CASE(SAME, 32, 32, 21, 21, 6, 2, PPO_NW32)    // 126 px = 8 tiles -> 4 groups of 2: 1 per wave
+    PPO_CONV_CASE(SAME, 32, 32, 16, 16, 8, 2, PPO_NW32)    // 128 px = 8 tiles
+    PPO_CONV_CASE(SAME, 32, 32, 11, 11, 11, 2, PPO_NW32)   // 121 px = 8 tiles
+    PPO_CONV_CASE(SAME, 32, 32, 8, 8, 8, 1, PPO_NW32)      // 64 px = 4 tiles: 1 per wave
 #undef PPO_CONV_CASE
     return fail(PPO_E_INVALID, "conv3x3: unsupported geometry cin=%d cout=%d h=%d w=%d transposed=%d", cin,
                 cout, h, w_, (int)TRANSPOSED);

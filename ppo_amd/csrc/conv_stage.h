@@ -116,6 +116,104 @@ __device__ __forceinline__ void stage_band_dma(const float *__restrict__ src, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "Flat" band layout: a channel plane holds the band rows back to back with the IMAGE's row stride,
+//   s_dst[c * PLANE + G + r * W + x] = f(src[img][c][y0 + r - 1][x]),  r < ROWS (one halo row above / below),
+// i.e. no halo COLUMNS: the consumer masks the x-1 / x+1 taps at the image's left / right edge instead.
+// Because global memory has the same row stride, the in-image part of a plane is ONE contiguous run, so the
+// DMA moves it with 16-byte requests (64 lanes x 4 floats = 256 floats per request) instead of one 4-byte
+// request per row: 4-8x fewer requests, and request issue was what bounded the convolutions
+// (tools/dma16_probe.hip: the 16-byte form costs the same to issue and accepts 4-byte-aligned addresses on
+// both sides).  G floats of guard before and after the rows keep the masked edge reads inside the plane.
+
+// Register path (uint8 observations: /255 fused).  Same mapping idea as stage_band.
+template <int C, int CP, int H, int W, int ROWS, int PLANE, int G, int IN_MODE, int NWAVES>
+__device__ __forceinline__ void stage_band_flat(const void *__restrict__ src_, int img, int y0,
+                                                float *__restrict__ s_dst, int tid)
+{
+    constexpr int LG = W <= 16 ? 16 : (W <= 32 ? 32 : 64);
+    constexpr int RPI = 64 / LG;
+    constexpr int NPASS = (W + 63) / 64;
+    constexpr int RSTEP = NWAVES * RPI;
+    constexpr int RB = (ROWS + RSTEP - 1) / RSTEP;
+    constexpr int Q = CP * RB * NPASS;
+    constexpr int U = 8;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int sub = lane / LG;
+    const int col0 = lane % LG;
+    const int rw = wave * RPI + sub;
+#pragma unroll 1
+    for (int q0 = 0; q0 < Q; q0 += U) {
+        float v[U];
+        int off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;  // wave-uniform
+            const int pass = q % NPASS;
+            const int qq = q / NPASS;
+            const int c = qq / RB;
+            const int r = (qq % RB) * RSTEP + rw;
+            const int col = col0 + 64 * pass;
+            const bool in_lds = q < Q && r < ROWS && col < W;
+            const int gy = y0 + r - 1;
+            off[u] = in_lds ? c * PLANE + G + r * W + col : -1;
+            v[u] = 0.f;
+            if (in_lds && c < C && gy >= 0 && gy < H) {
+                const size_t gi = ((size_t)(img * C + c) * H + gy) * W + col;
+                if (IN_MODE == IN_U8) v[u] = (float)static_cast<const uint8_t *>(src_)[gi];
+                else v[u] = static_cast<const float *>(src_)[gi];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (off[u] >= 0) {
+                float x = v[u];
+                if (IN_MODE == IN_U8) x = x / 255.0f;
+                if (IN_MODE == IN_RELU) x = fmaxf(x, 0.f);
+                s_dst[off[u]] = x;
+            }
+        }
+    }
+}
+
+// LDS-DMA path.  Wave w moves channels w, w + NWAVES, ...: per channel the in-image rows are one run of
+// n = rows * W floats -> n/4 lanes of 16-byte requests (256 floats each) plus one 4-byte request for the
+// n % 4 leftover floats (never over-reads the source, never over-writes the rows below).  Band rows outside
+// the image (first / last band of an image) are zeroed with plain LDS stores.  Padded channels (>= C) and
+// the guards are never written: the caller zeroes the whole region once.
+template <int C, int H, int W, int ROWS, int PLANE, int G, int NWAVES>
+__device__ __forceinline__ void stage_band_chunk_dma(const float *__restrict__ src, int img, int y0,
+                                                     float *__restrict__ s_dst, int tid)
+{
+    using gptr_t = const __attribute__((address_space(1))) void *;
+    using lptr_t = __attribute__((address_space(3))) void *;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r_lo = y0 >= 1 ? 0 : 1 - y0;                          // first band row inside the image
+    const int r_hi = (y0 - 1 + ROWS) <= H ? ROWS : H - (y0 - 1);    // one past the last
+    const int n = (r_hi - r_lo) * W;                                // floats to move per channel
+    const int n4 = n >> 2;                                          // 16-byte lanes
+    const int tail = n & 3;
+    constexpr int MAXREQ = (ROWS * W / 4 + 63) / 64;
+#pragma unroll 1
+    for (int c = wave; c < C; c += NWAVES) {
+        const float *g0 = src + ((size_t)(img * C + c) * H + (y0 - 1 + r_lo)) * W;
+        float *l0 = s_dst + c * PLANE + G + r_lo * W;
+#pragma unroll
+        for (int q = 0; q < MAXREQ; ++q) {
+            if (q * 64 + lane < n4)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g0 + (q * 64 + lane) * 4), (lptr_t)(l0 + q * 256), 16, 0, 0);
+        }
+        if (lane < tail)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g0 + n4 * 4 + lane), (lptr_t)(l0 + n4 * 4), 4, 0, 0);
+        if (r_lo > 0)
+            for (int x = lane; x < r_lo * W; x += 64) s_dst[c * PLANE + G + x] = 0.f;
+        if (r_hi < ROWS)
+            for (int x = lane; x < (ROWS - r_hi) * W; x += 64) s_dst[c * PLANE + G + r_hi * W + x] = 0.f;
+    }
+}
+
 template <int WORDS, int NTHREADS>
 __device__ __forceinline__ void zero_lds(float *__restrict__ s, int tid)
 {
