@@ -229,10 +229,11 @@ def main():
     runner = rollout.Runner(model, logger.Logger(quiet=True))
     runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
     runner.reset()
-    # dominant kernel of the step (profiles/: largest total time): weight gradient of the 16->16 42x42 convs
-    probe = CallProbe(model.policy_net, "ppo_conv3x3_backward_weight_f32",
-                      lambda c: (c[8], c[9], c[10], c[11]) == (16, 16, 42, 42))
-    probe_flops = 2 * 9 * 16 * 16 * 42 * 42 * mb
+    # dominant kernel of the step (profiles/r01e: largest total time): the 32->32 21x21 forward convolution of the
+    # residual blocks, conv3x3_kernel<32,32,21,21,..,IN_RELU>; the train-minibatch launches (n == mb) are timed
+    probe = CallProbe(model.policy_net, "ppo_conv3x3_forward_f32",
+                      lambda c: c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (mb, 32, 32, 21, 21))
+    probe_flops = 2 * 9 * 32 * 32 * 21 * 21 * mb
 
     def iteration():
         runner.generate_rollout()
@@ -286,7 +287,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": "conv3x3_wgrad_kernel<16,16,42,42> (+ its slab reduce, one C-ABI call)",
+                     "kernel": "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)",
                      "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
                      "launches_timed": len(probe.events)},
         "phase_seconds_per_step": {k: round(v / a.steps, 4) for k, v in phase.items()},
