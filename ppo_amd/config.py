@@ -168,6 +168,7 @@ class Config:
         self.run_name = "run"
         self.restore = "never"
         self.checkpoint_every = int(10e6)
+        self.checkpoint_compression = True  # :726
         self.workers = -1              # :722
         self.threads = 2               # :723
         self.precision = "medium"      # :764
@@ -223,6 +224,7 @@ class Config:
         a("--run_name", type=str, default=self.run_name)
         a("--restore", type=str, default=self.restore, help="[never|auto|always]")
         a("--checkpoint_every", type=int, default=self.checkpoint_every)
+        a("--checkpoint_compression", type=str2bool, nargs="?", const=True, default=True)
         a("--workers", type=int, default=self.workers)
         a("--threads", type=int, default=self.threads)
         a("--precision", type=str, default=self.precision, help="[low|medium|high]; all run exact fp32 here")

@@ -120,11 +120,11 @@ def train(model, log: Logger):
 
 
 def get_checkpoints(path):
-    """Newest first: [(epoch_M, filename)] for files named checkpoint-XXXM-params.pt (rl/rollout.py:460-470)."""
+    """Newest first: [(epoch_M, filename)] for files named checkpoint-XXXM-params.pt[.gz] (rl/rollout.py:460-470)."""
     out = []
     if path and os.path.isdir(path):
         for f in os.listdir(path):
-            if f.startswith("checkpoint-") and f.endswith("M-params.pt"):
+            if f.startswith("checkpoint-") and (f.endswith("M-params.pt") or f.endswith("M-params.pt.gz")):
                 try:
                     out.append((int(f[len("checkpoint-"):f.index("M-")]), f))
                 except ValueError:

@@ -582,17 +582,26 @@ class Runner:
         return out
 
     # ------------------------------------------------------------------ checkpoints (rl/rollout.py:394-517)
-    def save_checkpoint(self, filename, step, disable_log=False, disable_replay=False, disable_env_state=False):
+    def save_checkpoint(self, filename, step, disable_log=False, disable_replay=False, disable_env_state=False,
+                        disable_optimizer=False):
+        """Model under the reference's state_dict names, optimiser states, counters, env / wrapper state;
+        gzip container when --checkpoint_compression (file name + '.gz').  Returns the path written."""
+        from . import checkpoint
         data = {"step": step, "ep_count": self.ep_count, "batch_counter": self.batch_counter,
-                "model_state_dict": self.model.state_dict(),
-                "policy_optimizer_state_dict": self.policy_optimizer.state_dict()}
-        if self.dual:
-            data["value_optimizer_state_dict"] = self.value_optimizer.state_dict()
-            data["distil_optimizer_state_dict"] = self.distil_optimizer.state_dict()
-        torch.save(data, filename)
+                "model_state_dict": dict(self.model.state_dict()), "sample_calls": self._sample_calls}
+        if not disable_optimizer:
+            data["policy_optimizer_state_dict"] = self.policy_optimizer.state_dict()
+            if self.dual:
+                data["value_optimizer_state_dict"] = self.value_optimizer.state_dict()
+                data["distil_optimizer_state_dict"] = self.distil_optimizer.state_dict()
+        if not disable_env_state and self.vec_env is not None:
+            data["env_state"] = checkpoint.save_env_state(self.vec_env)
+        return checkpoint.save(data, filename, bool(args.checkpoint_compression))
 
     def load_checkpoint(self, checkpoint_path):
-        cp = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        """Restores model, optimisers, counters and env state; returns the env step (rl/rollout.py:472-517)."""
+        from . import checkpoint
+        cp = checkpoint.load(checkpoint_path)
         self.model.load_state_dict(cp["model_state_dict"])
         for key, opt in (("policy_optimizer_state_dict", self.policy_optimizer),
                          ("value_optimizer_state_dict", self.value_optimizer if self.dual else None),
@@ -602,4 +611,7 @@ class Runner:
         self.step = cp["step"]
         self.ep_count = cp.get("ep_count", 0)
         self.batch_counter = cp.get("batch_counter", 0)
+        self._sample_calls = cp.get("sample_calls", 0)
+        if cp.get("env_state") and self.vec_env is not None:
+            checkpoint.restore_env_state(self.vec_env, cp["env_state"])
         return self.step
