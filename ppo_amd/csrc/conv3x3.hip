@@ -91,9 +91,22 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
 
     // ---- weights: the MFMA A operand of K step s is the same for every pixel tile, so each lane keeps
     // its A values for ALL steps in registers for the lifetime of the workgroup (NT * KS VGPRs: 36 for
-    // 16->16, 144 for 32->32) — loaded once, all requests in flight together; the weights (<= 36 KB)
-    // are L1/L2-resident.  No weight image in LDS, no LDS reads for A, no staging barrier.
+    // 16->16, 144 for 32->32) for the lifetime of the workgroup: no LDS reads for A in the K loop.
+    // They get there through LDS: the raw [O][I][3][3] tensor is copied in with coalesced loads (rows padded
+    // to an odd stride so the per-lane gather below is bank-conflict free), then each lane picks its values.
+    // (Gathering straight from global memory cost ~64 cache lines per load instruction: measured ~8 us of a
+    // 38 us launch for the 32->32 layers, all of it before the first MFMA.)
     constexpr int KS = 9 * (C::CINP / 4);
+    constexpr int WR = TRANSPOSED ? CIN : COUT;        // rows of the raw tensor
+    constexpr int WL = (TRANSPOSED ? COUT : CIN) * 9;  // row length
+    constexpr int WLP = WL | 1;                        // odd LDS row stride
+    // The transposed (backward-data) gather already touches few cache lines per request (lanes step through
+    // the contiguous [I][3][3] part of the tensor) and measured slightly faster straight from global memory.
+    constexpr bool VIA_LDS = !TRANSPOSED;
+    if constexpr (VIA_LDS) {
+        for (int i = tid; i < WR * WL; i += kConvThreads) smem[(i / WL) * WLP + i % WL] = w[i];
+        __syncthreads();
+    }
     float wa[C::NT][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -105,10 +118,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             float v = 0.f;
             if (ci < CIN && co < COUT)
                 v = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
-                               : w[((size_t)co * CIN + ci) * 9 + tap];
+                               : smem[co * WLP + ci * 9 + tap];
             wa[n][s] = v;
         }
     }
+    if constexpr (VIA_LDS) __syncthreads();  // every lane has its weights: the region is reused for the input bands
     // this lane's bias values (channels n*16 + g*4 + r), loaded once
     float bias_r[C::NT][4];
 #pragma unroll
@@ -316,13 +330,16 @@ int launch_conv(const void *in, const float *w, const float *bias, const float *
     using C = ConvCfg<CIN, COUT, H, W, TR, IN_MODE != IN_U8>;
     auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED>;
     constexpr int kConvThreads = NW * 64;
+    // the band buffers, or the padded weight image the prologue stages through the same region
+    constexpr size_t kWeightImage = (size_t)(TRANSPOSED ? CIN : COUT) * (((TRANSPOSED ? COUT : CIN) * 9) | 1) * 4;
+    constexpr size_t kLdsBytes = C::LDS_BYTES > kWeightImage ? C::LDS_BYTES : kWeightImage;
     static int wg_per_cu = 0;  // resident workgroups per CU (LDS- and VGPR-limited), queried once
     if (wg_per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
         int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kConvThreads, C::LDS_BYTES);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kConvThreads, kLdsBytes);
         if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3: occupancy query: %s", hipGetErrorString(e));
         wg_per_cu = nb < 1 ? 1 : (nb > 24 / NW ? 24 / NW : nb);
 #ifdef PPO_TUNE_WG_PER_CU  // tools/conv_tune experiment build only
@@ -332,7 +349,7 @@ int launch_conv(const void *in, const float *w, const float *bias, const float *
     const int n_items = n_images * C::NBANDS;
     int grid = 256 * wg_per_cu;
     if (grid > n_items) grid = n_items;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kConvThreads), C::LDS_BYTES, st, in, w, bias, residual, mask_src, out,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kConvThreads), kLdsBytes, st, in, w, bias, residual, mask_src, out,
                        n_images);
     return check_launch("conv3x3_kernel");
 }
