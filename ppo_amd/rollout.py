@@ -257,12 +257,20 @@ class Runner:
         P = len(parts)
         if len(self._step_events) < P:
             self._step_events = [torch.cuda.Event() for _ in range(P)]
-        events = self._step_events
+            self._copy_events = [torch.cuda.Event() for _ in range(P)]
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        events, copy_events, copy_stream = self._step_events, self._copy_events, self._copy_stream
+        main = torch.cuda.current_stream()
+        copy_stream.wait_stream(main)  # earlier readers of all_obs (the previous train phase) are done
 
         def enqueue(i, t):
-            # H2D of group i's observations (pinned -> HBM), policy + sampling, actions D2H; all async
+            # H2D of group i's observations (pinned -> HBM) on the copy stream, so it runs on a DMA engine
+            # under the other group's policy step; then policy + sampling, actions D2H; all async
             lo, hi = bounds[i], bounds[i + 1]
-            self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
+            with torch.cuda.stream(copy_stream):
+                self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
+                copy_events[i].record()
+            main.wait_event(copy_events[i])
             self._policy_step(t, lo, hi)
             if t < N:
                 self._actions_host[lo:hi].copy_(self.actions[t, lo:hi], non_blocking=True)
