@@ -28,10 +28,19 @@ namespace {
 
 constexpr int pad_mod32(int v, int target) { return v + ((target - v % 32) + 32) % 32; }
 
+#ifndef PPO_STAMP  // the stamp macros come from conv3x3.hip in the tools/conv_tune -DPPO_TUNE_STAMPS build
+#define PPO_STAMP(var)
+#define PPO_STAMP_ADD(slot, t1, t0)
+#endif
+// Double-buffered staging pays where the bands arrive by LDS-DMA and a workgroup sees several items; uint8
+// observations are staged through registers (the copy cannot overlap the K loop) and the 11x11 / 8x8 layers
+// are one item per workgroup (measured: 62 vs 76 us and 20.9 vs 21.8 us single-buffered).
+template <int IN_MODE, int NBANDS>
+constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : 2; }
 constexpr int kWgradWaves = 8;
 constexpr int kWgradKG = kWgradWaves / 4;  // K-split groups
 
-template <int CIN, int COUT, int H, int W, int TR>
+template <int CIN, int COUT, int H, int W, int TR, int NBUF_>
 struct WgradCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;
     static constexpr int MTC = COUT / 16;
@@ -50,36 +59,69 @@ struct WgradCfg {
     static constexpr int LDS_X = (CINP + 2) * XPLANE;  // + ones plane + zeros plane
     static constexpr int LDS_D = COUT * DPLANE;
     static constexpr int LDS_RED = COUT * JP;  // cross-K-group reduction image (reuses the staging space)
-    static constexpr int LDS_WORDS = (LDS_X + LDS_D) > LDS_RED ? (LDS_X + LDS_D) : LDS_RED;
+    static constexpr int NBUF = NBUF_;              // staging buffers: 2 = the next item's bands are in flight
+    static constexpr int LDS_BUF = LDS_X + LDS_D;   //   (LDS-DMA) while this item's K loop runs, one barrier per item
+    static constexpr int LDS_WORDS = NBUF * LDS_BUF > LDS_RED ? NBUF * LDS_BUF : LDS_RED;
     static constexpr size_t LDS_BYTES = (size_t)LDS_WORDS * 4;
     static_assert(COUT % 16 == 0, "COUT must be a multiple of 16");
 };
 
-// The K loop for a wave that owns NTW tiles.  Returns through acc.
-template <class C, int NTW, bool RELU>
+// The K loop of K-split group KGI for a wave that owns NTW tiles.  Fully unrolled: the step range of a group
+// is a compile-time constant, so every LDS offset is an immediate off a per-lane base register, and the
+// operands of step i+PF are requested before the MFMAs of step i issue (the rolled loop the compiler produced
+// from a runtime range exposed the whole LDS latency on every step: 58 % of the MFMA rate in its K loop).
+template <class C, int NTW, bool RELU, int KGI>
 __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, const float *__restrict__ s_d,
-                                             const int (&joff)[C::NTW_MAX], int aoff, int g, int s_begin, int s_end,
+                                             const int (&joff)[C::NTW_MAX], int aoff, int g,
                                              f32x4 (&acc)[C::MTC][C::NTW_MAX])
 {
     constexpr int SPR = C::PWD / 4;  // steps per row
-#pragma unroll 4
-    for (int s = s_begin; s < s_end; ++s) {
-        const int r = s / SPR;               // wave-uniform
-        const int pd = 4 * s;                // dy rows are PWD = 4*SPR wide: linear in s
-        const int px = 4 * s + 2 * r + g;    // x rows are PWD + 2 wide
-        float a[C::MTC], b[NTW];
+    constexpr int S0 = KGI * C::STEPS / kWgradKG, S1 = (KGI + 1) * C::STEPS / kWgradKG;
+    constexpr int LEN = S1 - S0;
+    constexpr int PF = 2;
+    float a[PF + 1][C::MTC], b[PF + 1][NTW];
+    int xb[NTW];
 #pragma unroll
-        for (int m = 0; m < C::MTC; ++m) a[m] = s_d[m * 16 * C::DPLANE + aoff + pd];
+    for (int t = 0; t < NTW; ++t) xb[t] = joff[t] + g;
+    auto load = [&](int i, float (&aa)[C::MTC], float (&bb)[NTW]) {
+        const int s = S0 + i;
+        const int pd = 4 * s;                     // dy rows are PWD = 4*SPR wide: linear in s
+        const int px = 4 * s + 2 * (s / SPR);     // x rows are PWD + 2 wide
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t] = s_x[joff[t] + px];
-        if (RELU) {  // the band was staged raw by LDS-DMA: the forward's ReLU-on-load is applied here
+        for (int m = 0; m < C::MTC; ++m) aa[m] = s_d[m * 16 * C::DPLANE + aoff + pd];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) b[t] = relu1(b[t]);
+        for (int t = 0; t < NTW; ++t) bb[t] = s_x[xb[t] + px];
+    };
+#pragma unroll
+    for (int i = 0; i < PF && i < LEN; ++i) load(i, a[i], b[i]);
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+        if (i + PF < LEN) load(i + PF, a[(i + PF) % (PF + 1)], b[(i + PF) % (PF + 1)]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            float bv = b[i % (PF + 1)][t];
+            if (RELU) bv = relu1(bv);  // the band was staged raw by LDS-DMA: the forward's ReLU-on-load is applied here
+#pragma unroll
+            for (int m = 0; m < C::MTC; ++m) acc[m][t] = mfma16(a[i % (PF + 1)][m], bv, acc[m][t]);
         }
-#pragma unroll
-        for (int m = 0; m < C::MTC; ++m)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// dispatch on the (wave-uniform) K group and tile count of this wave
+template <class C, bool RELU>
+__device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, const float *__restrict__ s_d,
+                                              const int (&joff)[C::NTW_MAX], int aoff, int g, int wt, int kg,
+                                              f32x4 (&acc)[C::MTC][C::NTW_MAX])
+{
+    constexpr int NLO = C::NTW_MAX > 1 ? C::NTW_MAX - 1 : 1;
+    static_assert(kWgradKG == 2, "two K groups");
+    if (wt < C::REM) {
+        if (kg == 0) wgrad_k_loop<C, C::NTW_MAX, RELU, 0>(s_x, s_d, joff, aoff, g, acc);
+        else wgrad_k_loop<C, C::NTW_MAX, RELU, 1>(s_x, s_d, joff, aoff, g, acc);
+    } else if (C::NTW_MAX > 1) {
+        if (kg == 0) wgrad_k_loop<C, NLO, RELU, 0>(s_x, s_d, joff, aoff, g, acc);
+        else wgrad_k_loop<C, NLO, RELU, 1>(s_x, s_d, joff, aoff, g, acc);
     }
 }
 
@@ -88,7 +130,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
                                                                         const float *__restrict__ dy,
                                                                         float *__restrict__ partial, int n_images)
 {
-    using C = WgradCfg<CIN, COUT, H, W, TR>;
+    using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
     extern __shared__ __align__(16) float smem[];
     float *s_x = smem;
     float *s_d = smem + C::LDS_X;
@@ -122,26 +164,49 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
 
     // zero everything once (halo columns, padded channels and padded dy columns are never written by the
     // LDS-DMA staging), then the constant planes
-    zero_lds<C::LDS_X + C::LDS_D, kWgradWaves * 64>(smem, tid);
+    zero_lds<C::NBUF * C::LDS_BUF, kWgradWaves * 64>(smem, tid);
     __syncthreads();
-    for (int i = tid; i < C::XPLANE; i += kWgradWaves * 64) s_x[C::CINP * C::XPLANE + i] = 1.0f;
+    for (int b = 0; b < C::NBUF; ++b)
+        for (int i = tid; i < C::XPLANE; i += kWgradWaves * 64) s_x[b * C::LDS_BUF + C::CINP * C::XPLANE + i] = 1.0f;
 
-    const int s_begin = kg * C::STEPS / kWgradKG;
-    const int s_end = (kg + 1) * C::STEPS / kWgradKG;
     const int n_items = n_images * C::NBANDS;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    auto stage = [&](int item, float *bx, float *bd) {
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
-        __syncthreads();
         if constexpr (IN_MODE == IN_U8)
-            stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, s_x, tid);
+            stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, bx, tid);
         else
-            stage_band_dma<CIN, H, W, C::ROWS, C::PWX, C::XPLANE, 1, kWgradWaves>(static_cast<const float *>(in_), img, y0, s_x, tid);
-        stage_band_dma<COUT, H, W, TR, C::PWD, C::DPLANE, 0, kWgradWaves>(dy, img, y0, s_d, tid);
-        __syncthreads();
-        constexpr bool RELU = IN_MODE == IN_RELU;
-        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU>(s_x, s_d, joff, aoff, g, s_begin, s_end, acc);
-        else if (C::NTW_MAX > 1) wgrad_k_loop<C, (C::NTW_MAX > 1 ? C::NTW_MAX - 1 : 1), RELU>(s_x, s_d, joff, aoff, g, s_begin, s_end, acc);
+            stage_band_dma<CIN, H, W, C::ROWS, C::PWX, C::XPLANE, 1, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
+        stage_band_dma<COUT, H, W, TR, C::PWD, C::DPLANE, 0, kWgradWaves>(dy, img, y0, bd, tid);
+    };
+    constexpr bool RELU = IN_MODE == IN_RELU;
+    if constexpr (C::NBUF == 2) {
+        int buf = 0;
+        if ((int)blockIdx.x < n_items) stage(blockIdx.x, s_x, s_d);
+        for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+            const float *bx = s_x + buf * C::LDS_BUF, *bd = s_d + buf * C::LDS_BUF;
+            PPO_STAMP(t_top)
+            __syncthreads();  // this item's bands have landed (vmcnt(0)); every wave is done with the other buffer
+            PPO_STAMP(t_bar)
+            if (item + (int)gridDim.x < n_items)
+                stage(item + gridDim.x, s_x + (buf ^ 1) * C::LDS_BUF, s_d + (buf ^ 1) * C::LDS_BUF);
+            PPO_STAMP(t_staged)
+            wgrad_k_loops<C, RELU>(bx, bd, joff, aoff, g, wt, kg, acc);
+            PPO_STAMP(t_end)
+            PPO_STAMP_ADD(0, t_bar, t_top)      // barrier wait
+            PPO_STAMP_ADD(1, t_staged, t_bar)   // DMA issue of the next item
+            PPO_STAMP_ADD(2, t_end, t_staged)   // K loop
+            PPO_STAMP_ADD(4, t_end, t_top)      // whole item
+            if (lane == 0) { PPO_STAMP_ADD(5, 1ull, 0ull) }
+            buf ^= 1;
+        }
+    } else {
+        for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+            __syncthreads();
+            stage(item, s_x, s_d);
+            __syncthreads();
+            wgrad_k_loops<C, RELU>(s_x, s_d, joff, aoff, g, wt, kg, acc);
+        }
     }
 
     // fold the K groups through LDS (fixed order), then one slab per workgroup:
@@ -254,7 +319,7 @@ template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
 int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *workspace, size_t workspace_bytes,
                  int n_images, int accumulate, hipStream_t st)
 {
-    using C = WgradCfg<CIN, COUT, H, W, TR>;
+    using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
     auto kern = conv3x3_wgrad_kernel<CIN, COUT, H, W, TR, IN_MODE>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -90,7 +90,7 @@ int main(int argc, char **argv)
                      g.cin, g.cout, g.hw, g.hw);
             printf("%-34s %10.1f %10.1f\n", name, us, flops / us / 1e6);
 #ifdef PPO_TUNE_STAMPS
-            if (which < 2) {
+            if (which <= 2) {
                 static std::vector<unsigned long long> all(8 * 8 * 1024), zeros(8 * 8 * 1024, 0);
                 CK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(ppo::ppo_tune_stamps), all.size() * 8));
                 CK(hipMemcpyToSymbol(HIP_SYMBOL(ppo::ppo_tune_stamps), zeros.data(), zeros.size() * 8));
