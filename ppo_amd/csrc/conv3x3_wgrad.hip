@@ -38,7 +38,6 @@ constexpr int pad_mod32(int v, int target) { return v + ((target - v % 32) + 32)
 template <int IN_MODE, int NBANDS>
 constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : 2; }
 constexpr int kWgradWaves = 8;
-constexpr int kWgradKG = kWgradWaves / 4;  // K-split groups
 
 template <int CIN, int COUT, int H, int W, int TR, int NBUF_>
 struct WgradCfg {
@@ -47,8 +46,15 @@ struct WgradCfg {
     static constexpr int NJ = 9 * CINP + 1;  // + the ones column (bias gradient)
     static constexpr int NTT = (NJ + 15) / 16;
     static constexpr int JP = NTT * 16;
-    static constexpr int NTW_MAX = (NTT + 3) / 4;  // tiles of waves with (wave % 4) < REM
-    static constexpr int REM = NTT % 4 == 0 ? 4 : NTT % 4;
+    // The 8 waves are WT tile owners x KG K-split groups.  WT is chosen so the N tiles divide (almost) evenly:
+    // 3 tiles (4 input channels) -> every wave owns all 3 and takes an eighth of K; 10 tiles (16 channels) ->
+    // 2 owners x 5 tiles, K in quarters; 19 tiles (32 channels) -> 4 owners x 5/5/5/4, K in halves.  (With a
+    // fixed 4 x 2 split the 10-tile layers ran 3/3/2/2 tiles per owner: a third of the K loop spent waiting at
+    // the item barrier.)
+    static constexpr int WT = NTT <= 4 ? 1 : (NTT <= 12 ? 2 : 4);
+    static constexpr int KG = kWgradWaves / WT;
+    static constexpr int NTW_MAX = (NTT + WT - 1) / WT;  // tiles of owners with index < REM
+    static constexpr int REM = NTT % WT == 0 ? WT : NTT % WT;
     static constexpr int PWD = (W + 3) / 4 * 4;
     static constexpr int PWX = PWD + 2;
     static constexpr int ROWS = TR + 2;
@@ -58,7 +64,7 @@ struct WgradCfg {
     static constexpr int STEPS = TR * (PWD / 4);
     static constexpr int LDS_X = (CINP + 2) * XPLANE;  // + ones plane + zeros plane
     static constexpr int LDS_D = COUT * DPLANE;
-    static constexpr int LDS_RED = COUT * JP;  // cross-K-group reduction image (reuses the staging space)
+    static constexpr int LDS_RED = (KG - 1) * COUT * JP;  // cross-K-group reduction images (reuse the staging space)
     static constexpr int NBUF = NBUF_;              // staging buffers: 2 = the next item's bands are in flight
     static constexpr int LDS_BUF = LDS_X + LDS_D;   //   (LDS-DMA) while this item's K loop runs, one barrier per item
     static constexpr int LDS_WORDS = NBUF * LDS_BUF > LDS_RED ? NBUF * LDS_BUF : LDS_RED;
@@ -76,7 +82,7 @@ __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, cons
                                              f32x4 (&acc)[C::MTC][C::NTW_MAX])
 {
     constexpr int SPR = C::PWD / 4;  // steps per row
-    constexpr int S0 = KGI * C::STEPS / kWgradKG, S1 = (KGI + 1) * C::STEPS / kWgradKG;
+    constexpr int S0 = KGI * C::STEPS / C::KG, S1 = (KGI + 1) * C::STEPS / C::KG;
     constexpr int LEN = S1 - S0;
     constexpr int PF = 2;
     float a[PF + 1][C::MTC], b[PF + 1][NTW];
@@ -109,19 +115,17 @@ __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, cons
 }
 
 // dispatch on the (wave-uniform) K group and tile count of this wave
-template <class C, bool RELU>
+template <class C, bool RELU, int KGI = 0>
 __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, const float *__restrict__ s_d,
                                               const int (&joff)[C::NTW_MAX], int aoff, int g, int wt, int kg,
                                               f32x4 (&acc)[C::MTC][C::NTW_MAX])
 {
     constexpr int NLO = C::NTW_MAX > 1 ? C::NTW_MAX - 1 : 1;
-    static_assert(kWgradKG == 2, "two K groups");
-    if (wt < C::REM) {
-        if (kg == 0) wgrad_k_loop<C, C::NTW_MAX, RELU, 0>(s_x, s_d, joff, aoff, g, acc);
-        else wgrad_k_loop<C, C::NTW_MAX, RELU, 1>(s_x, s_d, joff, aoff, g, acc);
-    } else if (C::NTW_MAX > 1) {
-        if (kg == 0) wgrad_k_loop<C, NLO, RELU, 0>(s_x, s_d, joff, aoff, g, acc);
-        else wgrad_k_loop<C, NLO, RELU, 1>(s_x, s_d, joff, aoff, g, acc);
+    if (kg == KGI) {
+        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU, KGI>(s_x, s_d, joff, aoff, g, acc);
+        else if (C::NTW_MAX > 1) wgrad_k_loop<C, NLO, RELU, KGI>(s_x, s_d, joff, aoff, g, acc);
+    } else if constexpr (KGI + 1 < C::KG) {
+        wgrad_k_loops<C, RELU, KGI + 1>(s_x, s_d, joff, aoff, g, wt, kg, acc);
     }
 }
 
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wt = wave & 3;   // owner of N tiles wt, wt+4, ...
-    const int kg = wave >> 2;  // K-split group
+    const int wt = wave % C::WT;  // owner of N tiles wt, wt + WT, ...
+    const int kg = wave / C::WT;  // K-split group
     const int l15 = lane & 15;
     const int g = lane >> 4;
 
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
     int joff[C::NTW_MAX];
 #pragma unroll
     for (int t = 0; t < C::NTW_MAX; ++t) {
-        const int j = (wt + 4 * t) * 16 + l15;
+        const int j = (wt + C::WT * t) * 16 + l15;
         const int tap = j / C::CINP;
         const int ci = j % C::CINP;
         joff[t] = j < 9 * C::CINP ? ci * C::XPLANE + (tap / 3) * C::PWX + (tap % 3)
@@ -209,32 +213,35 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
         }
     }
 
-    // fold the K groups through LDS (fixed order), then one slab per workgroup:
+    // fold the K groups through LDS: groups 1.. park their accumulators in images of their own, group 0
+    // adds them in group order (fixed order: deterministic), then one slab per workgroup:
     // partial[wg][co][j]; a lane holds rows g*4+r (co), column l15 (j) of each of its tiles
     float *s_red = smem;
+    __syncthreads();  // every wave is done reading the staging buffers
+    if (kg > 0) {
+        float *img = s_red + (size_t)(kg - 1) * COUT * C::JP;
+#pragma unroll
+        for (int m = 0; m < C::MTC; ++m)
+#pragma unroll
+            for (int t = 0; t < C::NTW_MAX; ++t)
+                if (wt + C::WT * t < C::NTT)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        img[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15] = acc[m][t][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
 #pragma unroll 1
-    for (int src = 1; src < kWgradKG; ++src) {
-        __syncthreads();
-        if (kg == src) {
+        for (int src = 1; src < C::KG; ++src) {
+            const float *img = s_red + (size_t)(src - 1) * COUT * C::JP;
 #pragma unroll
             for (int m = 0; m < C::MTC; ++m)
 #pragma unroll
                 for (int t = 0; t < C::NTW_MAX; ++t)
-                    if (wt + 4 * t < C::NTT)
+                    if (wt + C::WT * t < C::NTT)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            s_red[(m * 16 + g * 4 + r) * C::JP + (wt + 4 * t) * 16 + l15] = acc[m][t][r];
-        }
-        __syncthreads();
-        if (kg == 0) {
-#pragma unroll
-            for (int m = 0; m < C::MTC; ++m)
-#pragma unroll
-                for (int t = 0; t < C::NTW_MAX; ++t)
-                    if (wt + 4 * t < C::NTT)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[m][t][r] += s_red[(m * 16 + g * 4 + r) * C::JP + (wt + 4 * t) * 16 + l15];
+                            acc[m][t][r] += img[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15];
         }
     }
     if (kg == 0) {
@@ -243,10 +250,10 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const v
         for (int m = 0; m < C::MTC; ++m)
 #pragma unroll
             for (int t = 0; t < C::NTW_MAX; ++t)
-                if (wt + 4 * t < C::NTT)
+                if (wt + C::WT * t < C::NTT)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        slab[(m * 16 + g * 4 + r) * C::JP + (wt + 4 * t) * 16 + l15] = acc[m][t][r];
+                        slab[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15] = acc[m][t][r];
     }
 }
 
