@@ -117,6 +117,15 @@ int ppo_conv3x3_backward_data_f32(const float *dy, const float *weight, const fl
                                   void *stream);
 
 /*
+ * Stack-first convolution fused with the max-pool that follows it (rl/impala.py:104-105):
+ *   out = max_pool2d(conv3x3(f(in)) + bias, kernel 3, stride 2, padding 1),   [n,cout,(h+1)/2,(w+1)/2]
+ * bit-identical to ppo_conv3x3_forward_f32 followed by ppo_maxpool3x3s2_forward_f32, without the pre-pool
+ * map ever reaching HBM.  in_mode: PPO_IN_NONE or PPO_IN_U8.  argmax (nullable) as in the pool entry point.
+ */
+int ppo_conv3x3_pool_forward_f32(const void *in, int in_mode, const float *weight, const float *bias, float *out,
+                                 uint8_t *argmax, int n, int cin, int cout, int h, int w, void *stream);
+
+/*
  * Weight and bias gradient of the same convolution (torch autograd of nn.Conv2d):
  *   dweight[o,i,ky,kx] (+)= sum_{n,y,x} dy[n,o,y,x] * f(in[n,i,y+ky-1,x+kx-1])    dbias[o] (+)= sum dy[n,o,y,x]
  * `in`/in_mode: the forward convolution's input and load transform.  workspace: scratch of at

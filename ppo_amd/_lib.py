@@ -56,6 +56,7 @@ SIGNATURES = {
     "ppo_synth_env_reset": (_i, [_vp, _vp]),
     "ppo_synth_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ppo_conv3x3_pool_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),
     "ppo_tanh_backward_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "ppo_value_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),

@@ -395,6 +395,252 @@ int dispatch_conv(int cin, int cout, int h, int w_, const void *in, const float 
                 cout, h, w_, (int)TRANSPOSED);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stack-first convolution fused with the 3x3 / stride 2 / pad 1 max-pool that always follows it
+// (rl/impala.py:104-105: x = firstconv(x); x = max_pool2d(x, 3, 2, 1)).  The pre-pool map is the largest
+// tensor of the network (16 x 84 x 84 floats per sample: 27 % of the forward's HBM traffic when written and
+// read back) and nothing else ever needs it: the backward pass uses the pool's argmax only.  Here a
+// workgroup computes the 2*PR+1 convolution rows behind PR pooled rows into LDS, pools them from LDS and
+// writes only the pooled map (+ the uint8 argmax when training).  One convolution row per band is computed
+// twice (1/(2 PR) more MFMA work).  Same K loop, weight registers and band staging as conv3x3_kernel.
+template <int CIN, int COUT, int H, int W, int PR, bool DOUBLE>
+struct ConvPoolCfg {
+    static constexpr int CINP = (CIN + 3) / 4 * 4;
+    static constexpr int NT = (COUT + 15) / 16;
+    static constexpr int HO = (H + 1) / 2, WO = (W + 1) / 2;
+    static constexpr int NBANDS = (HO + PR - 1) / PR;
+    static constexpr int CR = 2 * PR + 1;       // convolution rows per band
+    static constexpr int ROWS = CR + 2;         // input rows per band
+    static constexpr int G = 4;
+    static constexpr int PLANE_RAW = ROWS * W + 2 * G;
+    static constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;  // = 16 (mod 32)
+    static constexpr int NPIX = CR * W;
+    static constexpr int OPLANE = NPIX + ((4 - NPIX % 16) + 16) % 16;  // = 4 (mod 16): conflict-free channel-strided stores
+    static constexpr int MTILES = (NPIX + 15) / 16;
+    static constexpr int LDS_IN = CINP * PLANE;
+    static constexpr int NBUF = DOUBLE ? 2 : 1;
+    static constexpr int LDS_OUT = COUT * OPLANE;
+    static constexpr size_t LDS_BYTES = (size_t)(NBUF * LDS_IN + LDS_OUT) * 4;
+};
+
+template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE>
+__global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__restrict__ in_, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ out,
+                                                              uint8_t *__restrict__ argmax, int n_images)
+{
+    constexpr bool DMA = IN_MODE != IN_U8;
+    constexpr int kWaves = NW, kThreads = NW * 64;
+    using C = ConvPoolCfg<CIN, COUT, H, W, PR, DMA>;
+    extern __shared__ __align__(16) float smem[];
+    float *s_out = smem + C::NBUF * C::LDS_IN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l15 = lane & 15;
+    const int g = lane >> 4;
+
+    // weights -> registers through LDS (see conv3x3_kernel)
+    constexpr int KS = 9 * (C::CINP / 4);
+    constexpr int WL = CIN * 9, WLP = WL | 1;
+    for (int i = tid; i < COUT * WL; i += kThreads) smem[(i / WL) * WLP + i % WL] = w[i];
+    __syncthreads();
+    float wa[C::NT][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int tap = s / (C::CINP / 4);
+        const int ci = (s % (C::CINP / 4)) * 4 + g;
+#pragma unroll
+        for (int n = 0; n < C::NT; ++n) {
+            const int co = n * 16 + l15;
+            wa[n][s] = (ci < CIN && co < COUT) ? smem[co * WLP + ci * 9 + tap] : 0.f;
+        }
+    }
+    __syncthreads();
+    float bias_r[C::NT][4];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = n * 16 + g * 4 + r;
+            bias_r[n][r] = (bias && co < COUT) ? bias[co] : 0.f;
+        }
+    if constexpr (DMA) {
+        zero_lds<C::NBUF * C::LDS_IN, kThreads>(smem, tid);
+        __syncthreads();
+    }
+
+    const int n_items = n_images * C::NBANDS;
+    auto stage = [&](int item, float *dst) {
+        const int img = item / C::NBANDS;
+        const int y0 = 2 * (item % C::NBANDS) * PR - 1;  // band row r holds image row y0 + r - 1 = 2*yo0 - 2 + r
+        if constexpr (DMA)
+            stage_band_chunk_dma<CIN, H, W, C::ROWS, C::PLANE, C::G, kWaves>(static_cast<const float *>(in_), img, y0, dst, tid);
+        else
+            stage_band_flat<CIN, C::CINP, H, W, C::ROWS, C::PLANE, C::G, IN_MODE, kWaves>(in_, img, y0, dst, tid);
+    };
+    if (DMA && (int)blockIdx.x < n_items) stage(blockIdx.x, smem);
+
+    constexpr int GROUPS = (C::MTILES + MT - 1) / MT;
+    constexpr int NGW = (GROUPS + kWaves - 1) / kWaves;
+    int buf = 0;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / C::NBANDS;
+        const int yo0 = (item % C::NBANDS) * PR;
+        if constexpr (DMA) {
+            __syncthreads();  // band landed; previous item's pooling reads of s_out are done
+            if (item + (int)gridDim.x < n_items) stage(item + gridDim.x, smem + (buf ^ 1) * C::LDS_IN);
+        } else {
+            __syncthreads();
+            stage(item, smem);
+            __syncthreads();
+        }
+        // ---- convolution rows -> s_out
+#pragma unroll 1
+        for (int q = 0; q < NGW; ++q) {
+            const int grp = wave + q * kWaves;
+            if (grp >= GROUPS) break;
+            f32x4 acc[C::NT][MT];
+            int base[MT], pixv[MT];
+            float hi_l[MT], hi_r[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int p = (grp * MT + m) * 16 + l15;
+                pixv[m] = p;
+                const int pc = p < C::NPIX ? p : 0;
+                base[m] = C::G + pc - 1 + g * C::PLANE + buf * C::LDS_IN;
+                hi_l[m] = (pc % W == 0) ? 0.f : INFINITY;
+                hi_r[m] = (pc % W == W - 1) ? 0.f : INFINITY;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            constexpr int PF = 2;
+            float b[PF + 1][MT];
+            auto load_step = [&](int s, float (&bb)[MT]) {
+                const int tap = s / (C::CINP / 4);
+                const int cs = s % (C::CINP / 4);
+                const int tap_off = (tap / 3) * W + (tap % 3);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) bb[m] = smem[base[m] + cs * 4 * C::PLANE + tap_off];
+            };
+#pragma unroll
+            for (int s = 0; s < PF; ++s) load_step(s, b[s]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + PF < KS) load_step(s + PF, b[(s + PF) % (PF + 1)]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float bv = b[s % (PF + 1)][m];
+                    const int kx = (s / (C::CINP / 4)) % 3;
+                    if (kx != 1) {
+                        const float hi = kx == 0 ? hi_l[m] : hi_r[m];
+                        bv = __builtin_amdgcn_fmed3f(bv, -hi, hi);
+                    }
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) acc[n][m] = mfma16(wa[n][s], bv, acc[n][m]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (pixv[m] < C::NPIX) {
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = n * 16 + g * 4 + r;
+                            if (co < COUT) s_out[co * C::OPLANE + pixv[m]] = acc[n][m][r] + bias_r[n][r];
+                        }
+                }
+        }
+        __syncthreads();  // all convolution rows of the band are in s_out
+        // ---- pool from LDS: ties to the first tap in row-major window order, padding excluded, NaN propagates
+        // (same rule as maxpool_fwd_kernel / F.max_pool2d)
+        const int pr_n = min(PR, C::HO - yo0);
+        const int n_out = COUT * pr_n * C::WO;
+        for (int o = tid; o < n_out; o += kThreads) {
+            const int xo = o % C::WO;
+            const int t = o / C::WO;
+            const int pr = t % pr_n;
+            const int co = t / pr_n;
+            const float *src = s_out + co * C::OPLANE;
+            float best = -INFINITY;
+            int best_tap = 0;
+            bool found = false;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int cr = 2 * pr + ky;                // convolution row inside the band
+                const int iy = 2 * (yo0 + pr) - 1 + ky;    // its image row
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = 2 * xo - 1 + kx;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                        const float v = src[cr * W + ix];
+                        if (!found || v > best || v != v) {
+                            best = v;
+                            best_tap = ky * 3 + kx;
+                            found = true;
+                        }
+                    }
+                }
+            }
+            const size_t oi = ((size_t)(img * COUT + co) * C::HO + (yo0 + pr)) * C::WO + xo;
+            out[oi] = best;
+            if (argmax) argmax[oi] = (uint8_t)best_tap;
+        }
+        if constexpr (DMA) buf ^= 1;
+    }
+}
+
+template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE>
+int launch_conv_pool(const void *in, const float *w, const float *bias, float *out, uint8_t *argmax, int n_images,
+                     hipStream_t st)
+{
+    using C = ConvPoolCfg<CIN, COUT, H, W, PR, IN_MODE != IN_U8>;
+    auto kern = conv3x3_pool_kernel<CIN, COUT, H, W, PR, MT, NW, IN_MODE>;
+    constexpr size_t kWeightImage = (size_t)COUT * ((CIN * 9) | 1) * 4;
+    constexpr size_t kLdsBytes = C::LDS_BYTES > kWeightImage ? C::LDS_BYTES : kWeightImage;
+    static_assert(kLdsBytes <= 160 * 1024, "band + pre-pool rows must fit the 160 KB of LDS");
+    static int wg_per_cu = 0;
+    if (wg_per_cu == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3_pool: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, kLdsBytes);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3_pool: occupancy query: %s", hipGetErrorString(e));
+        wg_per_cu = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+    }
+    const int n_items = n_images * C::NBANDS;
+    int grid = 256 * wg_per_cu;
+    if (grid > n_items) grid = n_items;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), kLdsBytes, st, in, w, bias, out, argmax, n_images);
+    return check_launch("conv3x3_pool_kernel");
+}
+
+template <int IN_MODE>
+int dispatch_conv_pool(int cin, int cout, int h, int w_, const void *in, const float *w, const float *bias, float *out,
+                       uint8_t *argmax, int n, hipStream_t st)
+{
+#define PPO_CP_CASE(ALLOWED, CI, CO, HH, WW, PR, MT)                                                       \
+    if constexpr (ALLOWED) {                                                                                 \
+        if (cin == CI && cout == CO && h == HH && w_ == WW)                                                  \
+            return launch_conv_pool<CI, CO, HH, WW, PR, MT, 8, IN_MODE>(in, w, bias, out, argmax, n, st);   \
+    }
+    constexpr bool FLOAT = IN_MODE == IN_NONE;
+    PPO_CP_CASE(true, 4, 16, 84, 84, 6, 3)     // 13 rows x 84 = 69 tiles -> 23 groups of 3
+    PPO_CP_CASE(true, 5, 16, 84, 84, 6, 3)
+    PPO_CP_CASE(true, 3, 16, 64, 64, 8, 3)     // 17 rows x 64 = 68 tiles
+    PPO_CP_CASE(true, 4, 16, 64, 64, 8, 3)
+    PPO_CP_CASE(FLOAT, 16, 32, 42, 42, 3, 3)   // 7 rows x 42 = 19 tiles -> 7 groups
+    PPO_CP_CASE(FLOAT, 16, 32, 32, 32, 4, 3)   // 9 rows x 32 = 18 tiles -> 6 groups
+    PPO_CP_CASE(FLOAT, 32, 32, 21, 21, 6, 3)   // 13 rows x 21 = 18 tiles
+    PPO_CP_CASE(FLOAT, 32, 32, 16, 16, 8, 3)   // 17 rows x 16 = 17 tiles
+#undef PPO_CP_CASE
+    return fail(PPO_E_INVALID, "conv3x3_pool: unsupported geometry cin=%d cout=%d h=%d w=%d in_mode=%d", cin, cout, h,
+                w_, IN_MODE);
+}
+
 }  // namespace
 }  // namespace ppo
 
@@ -426,4 +672,20 @@ extern "C" int ppo_conv3x3_backward_data_f32(const float *dy, const float *weigh
     // the transposed op contracts over the forward op's output channels
     return dispatch_conv<IN_NONE, true>(cout, cin, h, w, dy, weight, nullptr, dres, relu_src, dx, n,
                                         as_stream(stream));
+}
+
+extern "C" int ppo_conv3x3_pool_forward_f32(const void *in, int in_mode, const float *weight, const float *bias,
+                                            float *out, uint8_t *argmax, int n, int cin, int cout, int h, int w,
+                                            void *stream)
+{
+    using namespace ppo;
+    if (n < 0) return fail(PPO_E_INVALID, "ppo_conv3x3_pool_forward_f32: n < 0");
+    if (n == 0) return PPO_OK;
+    if (!in || !weight || !out) return fail(PPO_E_INVALID, "ppo_conv3x3_pool_forward_f32: null pointer");
+    hipStream_t st = as_stream(stream);
+    switch (in_mode) {
+        case IN_NONE: return dispatch_conv_pool<IN_NONE>(cin, cout, h, w, in, weight, bias, out, argmax, n, st);
+        case IN_U8: return dispatch_conv_pool<IN_U8>(cin, cout, h, w, in, weight, bias, out, argmax, n, st);
+    }
+    return fail(PPO_E_INVALID, "ppo_conv3x3_pool_forward_f32: in_mode %d (the stack-first convolution reads raw input)", in_mode);
 }

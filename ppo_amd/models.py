@@ -342,11 +342,12 @@ class DualHeadNet:
         acts = {"x": x}
         cur, cur_mode = x, (IN_U8 if x.dtype == torch.uint8 else IN_NONE)
         for si, (cin, cout, h, w, ho, wo) in enumerate(sp.stacks):
-            c = self._buf(f"{tag}c{si}", (B, cout, h, w))
-            self._conv(cur, cur_mode, f"encoder.stacks.{si}.firstconv", c, None, B, cin, cout, h, w)
+            # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
             p = self._buf(f"{tag}p{si}", (B, cout, ho, wo))
             idx = self._buf(f"{tag}idx{si}", (B, cout, ho, wo), torch.uint8) if train else None
-            self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
+            wname = f"encoder.stacks.{si}.firstconv"
+            self._call("ppo_conv3x3_pool_forward_f32", _p(cur), cur_mode, _p(self.params[wname + ".weight"]),
+                       _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
             acts[f"in{si}"], acts[f"idx{si}"] = cur, idx
             q = p
             for bi in range(sp.n_block):

@@ -107,3 +107,42 @@ def test_unsupported_geometry_is_an_error():
     out = torch.zeros(1, 8, 10, 10, device=dev)
     rc = _lib.load().ppo_conv3x3_forward_f32(_p(x), 0, _p(w), None, None, _p(out), 1, 7, 8, 10, 10, _lib.current_stream())
     assert rc == -1
+
+
+@pytest.mark.parametrize("cin,cout,hw,u8", [(4, 16, 84, True), (5, 16, 84, False), (3, 16, 64, True), (4, 16, 64, False),
+                                            (16, 32, 42, False), (16, 32, 32, False), (32, 32, 21, False),
+                                            (32, 32, 16, False)])
+@pytest.mark.parametrize("n", [1, 5, 130])
+def test_fused_conv_pool_equals_conv_then_pool_bitwise(cin, cout, hw, u8, n):
+    """ppo_conv3x3_pool_forward_f32 (stack-first conv + max-pool, the pre-pool map stays in LDS) must give
+    exactly what the two separate entry points give — same MFMA accumulation order, same pooling rule
+    (first maximum in row-major window order, padding excluded) — and match torch's conv2d + max_pool2d."""
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(cin * 1000 + hw + n)
+    if u8:
+        x = torch.randint(0, 256, (n, cin, hw, hw), generator=g, device=dev, dtype=torch.uint8)
+        mode, xf = 2, x.float() / 255.0
+    else:
+        x = torch.randn(n, cin, hw, hw, generator=g, device=dev)
+        mode, xf = 0, x
+    # quantised weights/bias make ties in the pooling windows likely (the tie rule is part of the contract)
+    w = (torch.randn(cout, cin, 3, 3, generator=g, device=dev) * 4).round() / 16
+    b = (torch.randn(cout, generator=g, device=dev) * 4).round() / 8
+    ho = (hw + 1) // 2
+    c = conv_fwd(x, w, b, None, mode)
+    p_ref = torch.empty(n, cout, ho, ho, device=dev)
+    i_ref = torch.empty(n, cout, ho, ho, device=dev, dtype=torch.uint8)
+    _lib.check(lib.ppo_maxpool3x3s2_forward_f32(_p(c), _p(p_ref), _p(i_ref), n, cout, hw, hw, _lib.current_stream()), "pool")
+    p = torch.full((n, cout, ho, ho), float("nan"), device=dev)
+    i = torch.full((n, cout, ho, ho), 255, device=dev, dtype=torch.uint8)
+    _lib.check(lib.ppo_conv3x3_pool_forward_f32(_p(x), mode, _p(w), _p(b), _p(p), _p(i), n, cin, cout, hw, hw,
+                                                _lib.current_stream()), "ppo_conv3x3_pool_forward_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_ref) and torch.equal(i, i_ref)
+    assert _close(p, F.max_pool2d(F.conv2d(xf, w, b, padding=1), 3, 2, 1))
+    # inference form: no argmax
+    p2 = torch.empty_like(p)
+    _lib.check(lib.ppo_conv3x3_pool_forward_f32(_p(x), mode, _p(w), _p(b), _p(p2), None, n, cin, cout, hw, hw,
+                                                _lib.current_stream()), "ppo_conv3x3_pool_forward_f32")
+    assert torch.equal(p2, p_ref)
