@@ -480,6 +480,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
             stage_band_flat<CIN, C::CINP, H, W, C::ROWS, C::PLANE, C::G, IN_MODE, kWaves>(in_, img, y0, dst, tid);
     };
     if (DMA && (int)blockIdx.x < n_items) stage(blockIdx.x, smem);
+    // uint8 observations: the next item's band waits in registers while this item computes
+    using FM = FlatMap<C::CINP, W, C::ROWS, kWaves>;
+    uint32_t raw[DMA ? 1 : FM::Q];
+    auto prefetch = [&](int item) {
+        if constexpr (!DMA)
+            band_flat_load<CIN, C::CINP, H, W, C::ROWS, IN_MODE, kWaves>(in_, item / C::NBANDS,
+                                                                         2 * (item % C::NBANDS) * PR - 1, tid, raw);
+    };
+    if (!DMA && (int)blockIdx.x < n_items) prefetch(blockIdx.x);
 
     constexpr int GROUPS = (C::MTILES + MT - 1) / MT;
     constexpr int NGW = (GROUPS + kWaves - 1) / kWaves;
@@ -491,8 +500,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
             __syncthreads();  // band landed; previous item's pooling reads of s_out are done
             if (item + (int)gridDim.x < n_items) stage(item + gridDim.x, smem + (buf ^ 1) * C::LDS_IN);
         } else {
-            __syncthreads();
-            stage(item, smem);
+            __syncthreads();  // previous item's readers are done with the band and s_out
+            band_flat_store<C::CINP, W, C::ROWS, C::PLANE, C::G, IN_MODE, kWaves>(raw, smem, tid);
+            if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
             __syncthreads();
         }
         // ---- convolution rows -> s_out
@@ -556,37 +566,40 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
         __syncthreads();  // all convolution rows of the band are in s_out
         // ---- pool from LDS: ties to the first tap in row-major window order, padding excluded, NaN propagates
         // (same rule as maxpool_fwd_kernel / F.max_pool2d)
+        // A wave pass covers RPW pooled rows of WO outputs (lane -> (row in pass, xo)); rows are (co, pr) pairs
+        // with pr fastest, so the only divisions are by compile-time constants.
+        constexpr int RPW = 64 / C::WO;
+        const int sub = lane / C::WO, xo = lane % C::WO;
         const int pr_n = min(PR, C::HO - yo0);
-        const int n_out = COUT * pr_n * C::WO;
-        for (int o = tid; o < n_out; o += kThreads) {
-            const int xo = o % C::WO;
-            const int t = o / C::WO;
-            const int pr = t % pr_n;
-            const int co = t / pr_n;
-            const float *src = s_out + co * C::OPLANE;
-            float best = -INFINITY;
-            int best_tap = 0;
-            bool found = false;
+        for (int u0 = wave * RPW; u0 < COUT * PR; u0 += kWaves * RPW) {
+            const int u = u0 + sub;
+            const int co = u / PR, pr = u % PR;
+            if (sub < RPW && co < COUT && pr < pr_n) {
+                const float *src = s_out + co * C::OPLANE + 2 * pr * W + 2 * xo - 1;  // window origin (cr = 2 pr, ix = 2 xo - 1)
+                const int yo = yo0 + pr;
+                float best = -INFINITY;
+                int best_tap = 0;
+                bool found = false;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int cr = 2 * pr + ky;                // convolution row inside the band
-                const int iy = 2 * (yo0 + pr) - 1 + ky;    // its image row
+                for (int ky = 0; ky < 3; ++ky) {
+                    const bool row_ok = (ky == 0) ? yo > 0 : (ky == 1 ? true : 2 * yo + 1 < H);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = 2 * xo - 1 + kx;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                        const float v = src[cr * W + ix];
-                        if (!found || v > best || v != v) {
-                            best = v;
-                            best_tap = ky * 3 + kx;
-                            found = true;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool col_ok = (kx == 0) ? xo > 0 : (kx == 1 ? true : 2 * xo + 1 < W);
+                        if (row_ok && col_ok) {
+                            const float v = src[ky * W + kx];
+                            if (!found || v > best || v != v) {
+                                best = v;
+                                best_tap = ky * 3 + kx;
+                                found = true;
+                            }
                         }
                     }
                 }
+                const size_t oi = ((size_t)(img * COUT + co) * C::HO + yo) * C::WO + xo;
+                out[oi] = best;
+                if (argmax) argmax[oi] = (uint8_t)best_tap;
             }
-            const size_t oi = ((size_t)(img * COUT + co) * C::HO + (yo0 + pr)) * C::WO + xo;
-            out[oi] = best;
-            if (argmax) argmax[oi] = (uint8_t)best_tap;
         }
         if constexpr (DMA) buf ^= 1;
     }

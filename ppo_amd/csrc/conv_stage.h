@@ -177,6 +177,69 @@ __device__ __forceinline__ void stage_band_flat(const void *__restrict__ src_, i
     }
 }
 
+// The same register path in two phases, so that a caller can issue the loads of the NEXT item before its
+// compute phase and write them to LDS after it (the loads' latency hides under the MFMAs): `raw` carries the
+// loaded bits untouched (no conversion, so nothing waits on the loads until band_flat_store).
+template <int CP, int W, int ROWS, int NWAVES>
+struct FlatMap {
+    static constexpr int LG = W <= 16 ? 16 : (W <= 32 ? 32 : 64);
+    static constexpr int RPI = 64 / LG;
+    static constexpr int NPASS = (W + 63) / 64;
+    static constexpr int RSTEP = NWAVES * RPI;
+    static constexpr int RB = (ROWS + RSTEP - 1) / RSTEP;
+    static constexpr int Q = CP * RB * NPASS;  // wave-uniform work items = registers per thread
+};
+
+template <int C, int CP, int H, int W, int ROWS, int IN_MODE, int NWAVES>
+__device__ __forceinline__ void band_flat_load(const void *__restrict__ src_, int img, int y0, int tid,
+                                               uint32_t (&raw)[FlatMap<CP, W, ROWS, NWAVES>::Q])
+{
+    using M = FlatMap<CP, W, ROWS, NWAVES>;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rw = wave * M::RPI + lane / M::LG;
+    const int col0 = lane % M::LG;
+#pragma unroll
+    for (int q = 0; q < M::Q; ++q) {
+        const int pass = q % M::NPASS;
+        const int qq = q / M::NPASS;
+        const int c = qq / M::RB;
+        const int r = (qq % M::RB) * M::RSTEP + rw;
+        const int col = col0 + 64 * pass;
+        const int gy = y0 + r - 1;
+        raw[q] = 0;
+        if (r < ROWS && col < W && c < C && gy >= 0 && gy < H) {
+            const size_t gi = ((size_t)(img * C + c) * H + gy) * W + col;
+            if (IN_MODE == IN_U8) raw[q] = static_cast<const uint8_t *>(src_)[gi];
+            else raw[q] = static_cast<const uint32_t *>(src_)[gi];
+        }
+    }
+}
+
+template <int CP, int W, int ROWS, int PLANE, int G, int IN_MODE, int NWAVES>
+__device__ __forceinline__ void band_flat_store(const uint32_t (&raw)[FlatMap<CP, W, ROWS, NWAVES>::Q],
+                                                float *__restrict__ s_dst, int tid)
+{
+    using M = FlatMap<CP, W, ROWS, NWAVES>;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rw = wave * M::RPI + lane / M::LG;
+    const int col0 = lane % M::LG;
+#pragma unroll
+    for (int q = 0; q < M::Q; ++q) {
+        const int pass = q % M::NPASS;
+        const int qq = q / M::NPASS;
+        const int c = qq / M::RB;
+        const int r = (qq % M::RB) * M::RSTEP + rw;
+        const int col = col0 + 64 * pass;
+        if (r < ROWS && col < W) {
+            float x;
+            if (IN_MODE == IN_U8) x = (float)raw[q] / 255.0f;
+            else x = __uint_as_float(raw[q]);
+            if (IN_MODE == IN_RELU) x = fmaxf(x, 0.f);
+            s_dst[c * PLANE + G + r * W + col] = x;
+        }
+    }
+}
+
 // LDS-DMA path.  Wave w moves channels w, w + NWAVES, ...: per channel the in-image rows are one run of
 // n = rows * W floats -> n/4 lanes of 16-byte requests (256 floats each) plus one 4-byte request for the
 // n % 4 leftover floats (never over-reads the source, never over-writes the rows below).  Band rows outside

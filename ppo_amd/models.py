@@ -12,6 +12,7 @@ torch is used for device memory, views and (on the CPU, at construction only) th
 parameter initialisers; no torch operator is on the forward/backward path.
 """
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -22,6 +23,9 @@ from . import _lib
 
 IN_NONE, IN_RELU, IN_U8 = _lib.PPO_IN_NONE, _lib.PPO_IN_RELU, _lib.PPO_IN_U8
 _ALIGN = 4  # floats: every parameter starts on a 16-byte boundary
+# bit i set: stack i runs its first convolution fused with the max-pool (bit-identical either way; the choice is
+# a measured one)
+FUSE_POOL_STACKS = int(os.environ.get("PPO_AMD_FUSE_POOL", "7"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -342,12 +346,17 @@ class DualHeadNet:
         acts = {"x": x}
         cur, cur_mode = x, (IN_U8 if x.dtype == torch.uint8 else IN_NONE)
         for si, (cin, cout, h, w, ho, wo) in enumerate(sp.stacks):
-            # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
             p = self._buf(f"{tag}p{si}", (B, cout, ho, wo))
             idx = self._buf(f"{tag}idx{si}", (B, cout, ho, wo), torch.uint8) if train else None
             wname = f"encoder.stacks.{si}.firstconv"
-            self._call("ppo_conv3x3_pool_forward_f32", _p(cur), cur_mode, _p(self.params[wname + ".weight"]),
-                       _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
+            if FUSE_POOL_STACKS >> si & 1:
+                # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
+                self._call("ppo_conv3x3_pool_forward_f32", _p(cur), cur_mode, _p(self.params[wname + ".weight"]),
+                           _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
+            else:
+                c = self._buf(f"{tag}c{si}", (B, cout, h, w))
+                self._conv(cur, cur_mode, wname, c, None, B, cin, cout, h, w)
+                self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
             acts[f"in{si}"], acts[f"idx{si}"] = cur, idx
             q = p
             for bi in range(sp.n_block):
