@@ -357,7 +357,11 @@ extern "C" int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu
     if (!A || !B || !C) return fail(PPO_E_INVALID, "ppo_gemm_f32: null pointer");
     if (ldc < N) return fail(PPO_E_INVALID, "ppo_gemm_f32: ldc < N");
     hipStream_t st = as_stream(stream);
-    if ((M <= 16 || N <= 16 || K <= 16) && (int64_t)M * N <= (1 << 22)) {
+    // The choice of kernel must not depend on the batch size, or a rollout forward (batch A) and a training
+    // forward (batch 256) of the same sample would round differently.  N and K of a forward product are model
+    // dimensions; M is the batch unless A is read transposed (a_sm == 1: a weight-gradient product dY^T X,
+    // where M is a model dimension and K the batch).
+    if ((N <= 16 || K <= 16 || (M <= 16 && a_sm == 1)) && (int64_t)M * N <= (1 << 22)) {
         GemmArgs q{A, B, C, bias, mask, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, relu_a, relu_b, K, 1, 0, 0};
         if (N <= kRowsMaxN && a_sk == 1 && b_sk == 1 && K <= 64 * kRowsMaxKPerLane) {
             hipLaunchKernelGGL(gemm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, q);

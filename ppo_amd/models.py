@@ -26,6 +26,8 @@ _ALIGN = 4  # floats: every parameter starts on a 16-byte boundary
 # bit i set: stack i runs its first convolution fused with the max-pool (bit-identical either way; the choice is
 # a measured one)
 FUSE_POOL_STACKS = int(os.environ.get("PPO_AMD_FUSE_POOL", "7"))
+# weight-gradient kernels on a second stream, overlapping the backward-data chain (0 = one stream)
+WGRAD_SIDE_STREAM = int(os.environ.get("PPO_AMD_WGRAD_STREAM", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -467,34 +469,50 @@ class DualHeadNet:
         self._linear_backward(acts["x"], sp.in_features, "encoder.fc1", da1, None)
 
     def _backward_impala(self, acts, dh):
+        """Backward through the encoder.  The weight gradients run on a second stream: a layer's wgrad and its
+        backward-data only share inputs, so the wgrad's ramp-up / tail overlaps the next backward-data kernel
+        instead of leaving the chip half empty (every kernel here is a persistent grid with a few-microsecond
+        prologue and a ragged tail).  Every gradient tensor has its own buffer within a pass, so the two
+        streams never reuse memory the other still reads; the main stream joins the side stream at the end."""
         sp, lib = self.spec, self.lib
         B, H = dh.shape
         flat = acts["flat"]
         # dense: dW = dh^T @ relu(flat); db = colsum(dh); dflat = (dh @ W) * (flat > 0)
         c_last, h_last, w_last = sp.out_shape
-        g = self._buf(f"g{len(sp.stacks) - 1}_a", (B, c_last, h_last, w_last))
+        g = self._buf(f"g{len(sp.stacks) - 1}_top", (B, c_last, h_last, w_last))
         self._linear_backward(flat, sp.flat, "encoder.dense", dh, g, relu_x=1, mask=flat)
+
+        main = torch.cuda.current_stream()
+        side = self._wgrad_side_stream() if WGRAD_SIDE_STREAM else None
+        n_wgrad = [0]
 
         def wgrad(x, mode, dy, wname, n, cin, cout, hh, ww):
             nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
             ws = self._ws("wgrad_ws", nbytes)
-            self._call("ppo_conv3x3_backward_weight_f32", _p(x), mode, _p(dy), _p(self.grads[wname + ".weight"]),
-                       _p(self.grads[wname + ".bias"]), _p(ws), nbytes, n, cin, cout, hh, ww, 0)
+            args_ = ("ppo_conv3x3_backward_weight_f32", _p(x), mode, _p(dy), _p(self.grads[wname + ".weight"]),
+                     _p(self.grads[wname + ".bias"]), _p(ws), nbytes, n, cin, cout, hh, ww, 0)
+            if side is None:
+                self._call(*args_)
+                return
+            ev = self._wgrad_events[n_wgrad[0]]
+            n_wgrad[0] += 1
+            ev.record(main)  # dy (and everything before it) is ready
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self._call(*args_)
 
         for si in reversed(range(len(sp.stacks))):
             cin, cout, hh, ww, ho, wo = sp.stacks[si]
-            slot = 0  # g currently lives in buffer g{si}_a
             for bi in reversed(range(sp.n_block)):
                 base = f"encoder.stacks.{si}.blocks.{bi}"
                 q_in, a = acts[f"q{si}_{bi}_in"], acts[f"a{si}_{bi}"]
                 # g = d loss / d (block output);  block: out = q_in + conv1(relu(conv0(relu(q_in))))
                 wgrad(a, IN_RELU, g, base + ".conv1", B, cout, cout, ho, wo)
-                da = self._buf(f"g{si}_da", (B, cout, ho, wo))
+                da = self._buf(f"g{si}_{bi}_da", (B, cout, ho, wo))
                 self._call("ppo_conv3x3_backward_data_f32", _p(g), _p(self.params[base + ".conv1.weight"]), _p(a), None,
                            _p(da), B, cout, cout, ho, wo)
                 wgrad(q_in, IN_RELU, da, base + ".conv0", B, cout, cout, ho, wo)
-                slot ^= 1  # ping-pong between the two gradient buffers of this resolution
-                gn = self._buf(f"g{si}_{'ab'[slot]}", (B, cout, ho, wo))
+                gn = self._buf(f"g{si}_{bi}_in", (B, cout, ho, wo))
                 self._call("ppo_conv3x3_backward_data_f32", _p(da), _p(self.params[base + ".conv0.weight"]), _p(q_in),
                            _p(g), _p(gn), B, cout, cout, ho, wo)
                 g = gn
@@ -505,9 +523,18 @@ class DualHeadNet:
             mode = IN_NONE if si > 0 else (IN_U8 if x_in.dtype == torch.uint8 else IN_NONE)
             wgrad(x_in, mode, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
             if si > 0:
-                g = self._buf(f"g{si - 1}_a", (B, cin, hh, ww))
+                g = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
                 self._call("ppo_conv3x3_backward_data_f32", _p(dc), _p(self.params[f"encoder.stacks.{si}.firstconv.weight"]),
                            None, None, _p(g), B, cin, cout, hh, ww)
+        if side is not None:
+            main.wait_stream(side)  # all weight gradients are in self.grad before anything reads it
+
+    def _wgrad_side_stream(self):
+        if getattr(self, "_wgrad_stream", None) is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            n = len(self.spec.stacks) * (1 + 2 * self.spec.n_block)
+            self._wgrad_events = [torch.cuda.Event() for _ in range(n)]
+        return self._wgrad_stream
 
     # ------------------------------------------------------------------ minibatch losses + optimiser
     def _train_forward(self, prev_state):
