@@ -288,12 +288,13 @@ class DualHeadNet:
         if rc != 0:
             _lib.check(rc, fn_name)
 
-    def _linear(self, x, k, wname, out, relu_x=0):
-        """out[B, n] = f(x)[B, k] @ W[n, k]^T + b  (torch.nn.Linear)."""
+    def _linear(self, x, k, wname, out, relu_x=0, tag=""):
+        """out[B, n] = f(x)[B, k] @ W[n, k]^T + b  (torch.nn.Linear).  `tag` keys the split-K workspace, so
+        forwards that run concurrently on different streams do not share it."""
         w = self.params[wname + ".weight"]
         B, n = x.shape[0], w.shape[0]
         ws_bytes = self.lib.ppo_gemm_workspace_bytes(B, n, k)
-        ws = self._ws("gemm_ws", ws_bytes)
+        ws = self._ws("gemm_ws" + tag, ws_bytes)
         self._call("ppo_gemm_f32", _p(x), k, 1, relu_x, _p(w), 1, k, 0, _p(self.params[wname + ".bias"]), None,
                    _p(out), n, B, n, k, _p(ws), ws_bytes)
 
@@ -312,39 +313,40 @@ class DualHeadNet:
         self._call("ppo_conv3x3_forward_f32", _p(x), mode, _p(self.params[wname + ".weight"]),
                    _p(self.params[wname + ".bias"]), _p(residual), _p(out), n, cin, cout, h, w)
 
-    def encode(self, x: torch.Tensor, train: bool):
+    def encode(self, x: torch.Tensor, train: bool, tag: Optional[str] = None):
         """x: [B, *input_dims] uint8 (scaled /255 on load; impala only) or float32.  Returns the dict of
         saved tensors; 'h' is the encoder output before the encoder activation, 'hact' its tanh when the
-        activation is tanh."""
+        activation is tanh.  `tag` names the scratch-buffer set ("t" training, "i" inference by default);
+        forwards that overlap on different streams use different tags."""
         sp = self.spec
+        tag = tag or ("t" if train else "i")
         if tuple(x.shape[1:]) != sp.input_dims:
             raise ValueError(f"expected input [B, {sp.input_dims}], got {tuple(x.shape)}")
         if x.dtype not in (torch.uint8, torch.float32) or not x.is_contiguous() or x.device != self.device:
             raise ValueError("input must be a contiguous uint8/float32 tensor on the model's device")
-        acts = self._encode_mlp(x, train) if self.encoder_kind == "mlp" else self._encode_impala(x, train)
+        acts = self._encode_mlp(x, train, tag) if self.encoder_kind == "mlp" else self._encode_impala(x, train, tag)
         if self.encoder_activation_fn == "tanh":
             h = acts["h"]
-            hact = self._buf(("t" if train else "i") + "hact", tuple(h.shape))
+            hact = self._buf(tag + "hact", tuple(h.shape))
             self._call("ppo_tanh_forward_f32", _p(h), _p(hact), h.numel())
             acts["hact"] = hact
         return acts
 
-    def _encode_mlp(self, x, train):
+    def _encode_mlp(self, x, train, tag):
         if x.dtype != torch.float32:
             raise ValueError("the mlp encoder takes float32 observations")
-        sp, B, tag = self.spec, x.shape[0], "t" if train else "i"
+        sp, B = self.spec, x.shape[0]
         z1 = self._buf(f"{tag}z1", (B, sp.hidden_units))
-        self._linear(x, sp.in_features, "encoder.fc1", z1)
+        self._linear(x, sp.in_features, "encoder.fc1", z1, tag=tag)
         a1 = self._buf(f"{tag}a1", (B, sp.hidden_units))
         self._call("ppo_tanh_forward_f32", _p(z1), _p(a1), z1.numel())
         h = self._buf(f"{tag}h", (B, sp.hidden_units))
-        self._linear(a1, sp.hidden_units, "encoder.fc2", h)
+        self._linear(a1, sp.hidden_units, "encoder.fc2", h, tag=tag)
         return {"x": x, "a1": a1, "h": h}
 
-    def _encode_impala(self, x, train):
+    def _encode_impala(self, x, train, tag):
         sp = self.spec
         B = x.shape[0]
-        tag = "t" if train else "i"
         acts = {"x": x}
         cur, cur_mode = x, (IN_U8 if x.dtype == torch.uint8 else IN_NONE)
         for si, (cin, cout, h, w, ho, wo) in enumerate(sp.stacks):
@@ -372,7 +374,7 @@ class DualHeadNet:
             cur, cur_mode = q, IN_NONE
         flat = cur.view(B, sp.flat)
         h = self._buf(f"{tag}h", (B, sp.hidden_units))
-        self._linear(flat, sp.flat, "encoder.dense", h, relu_x=1)
+        self._linear(flat, sp.flat, "encoder.dense", h, relu_x=1, tag=tag)
         acts["flat"], acts["h"] = flat, h
         return acts
 

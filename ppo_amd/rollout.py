@@ -190,7 +190,7 @@ class Runner:
         self.step = 0
 
     # ------------------------------------------------------------------ rollout
-    def _policy_step(self, t, lo=0, hi=None):
+    def _policy_step(self, t, lo=0, hi=None, tag="i"):
         """Forward + action sampling for envs [lo, hi) at env step t; writes those columns of row t of the
         rollout buffers.  The sampling counter is keyed by (rollout, t, env, action), so splitting the envs
         into groups does not change which action any env takes.  Dual architecture: the policy comes from
@@ -199,8 +199,8 @@ class Runner:
         hi = self.A if hi is None else hi
         B = hi - lo
         obs = self.all_obs[t, lo:hi]
-        hp = pol.heads(pol.encode(obs, train=False), "i")
-        hv = val.heads(val.encode(obs, train=False), "i") if self.dual else hp
+        hp = pol.heads(pol.encode(obs, train=False, tag=tag), tag)
+        hv = val.heads(val.encode(obs, train=False, tag=tag), tag) if self.dual else hp
         A, nA = self.A, self.n_actions
         final = t >= self.N
         seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + self.rank
@@ -259,9 +259,16 @@ class Runner:
             self._step_events = [torch.cuda.Event() for _ in range(P)]
             self._copy_events = [torch.cuda.Event() for _ in range(P)]
             self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._part_streams = [torch.cuda.Stream(device=self.device) for _ in range(P)]
         events, copy_events, copy_stream = self._step_events, self._copy_events, self._copy_stream
         main = torch.cuda.current_stream()
+        # each env group has its own compute stream (and scratch-buffer set), so the policy steps of the two
+        # groups overlap on the GPU: at half the batch most kernels expose fewer workgroups than there are CUs
+        streams = self._part_streams if P > 1 else [main]
         copy_stream.wait_stream(main)  # earlier readers of all_obs (the previous train phase) are done
+        for s_ in streams:
+            if s_ is not main:
+                s_.wait_stream(main)
 
         def enqueue(i, t):
             # H2D of group i's observations (pinned -> HBM) on the copy stream, so it runs on a DMA engine
@@ -270,11 +277,12 @@ class Runner:
             with torch.cuda.stream(copy_stream):
                 self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
                 copy_events[i].record()
-            main.wait_event(copy_events[i])
-            self._policy_step(t, lo, hi)
-            if t < N:
-                self._actions_host[lo:hi].copy_(self.actions[t, lo:hi], non_blocking=True)
-                events[i].record()
+            with torch.cuda.stream(streams[i]):
+                streams[i].wait_event(copy_events[i])
+                self._policy_step(t, lo, hi, tag=f"i{i}" if P > 1 else "i")
+                if t < N:
+                    self._actions_host[lo:hi].copy_(self.actions[t, lo:hi], non_blocking=True)
+                    events[i].record()
 
         def step_envs(i, t):
             # the one host wait of group i's step: its actions have landed; then step it on host cores
@@ -290,6 +298,9 @@ class Runner:
                 j, tj = (i + 1) % P, (t if i + 1 == P else t - 1)
                 if 0 <= tj < N:
                     step_envs(j, tj)  # overlaps the GPU work just queued for group i
+        for s_ in streams:
+            if s_ is not main:
+                main.wait_stream(s_)
         self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
 
     def _rollout_generic(self, env):
