@@ -13,7 +13,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libppo_amd.so")
+LIB_PATH = os.environ.get("PPO_AMD_LIB") or os.path.join(HERE, "lib", "libppo_amd.so")  # override: tuning builds
 
 PPO_TERM_NONE, PPO_TERM_U8, PPO_TERM_F32 = 0, 1, 2
 PPO_SCAN_AUTO, PPO_SCAN_COLUMNS, PPO_SCAN_TILES = 0, 1, 2

@@ -622,7 +622,7 @@ int launch_conv_pool(const void *in, const float *w, const float *bias, float *o
         int nb = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, kLdsBytes);
         if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3_pool: occupancy query: %s", hipGetErrorString(e));
-        wg_per_cu = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+        wg_per_cu = nb < 1 ? 1 : (nb > 3 ? 3 : nb);
     }
     const int n_items = n_images * C::NBANDS;
     int grid = 256 * wg_per_cu;
@@ -635,20 +635,33 @@ template <int IN_MODE>
 int dispatch_conv_pool(int cin, int cout, int h, int w_, const void *in, const float *w, const float *bias, float *out,
                        uint8_t *argmax, int n, hipStream_t st)
 {
-#define PPO_CP_CASE(ALLOWED, CI, CO, HH, WW, PR, MT)                                                       \
+#define PPO_CP_CASE(ALLOWED, CI, CO, HH, WW, PR, MT, NW)                                                   \
     if constexpr (ALLOWED) {                                                                                 \
         if (cin == CI && cout == CO && h == HH && w_ == WW)                                                  \
-            return launch_conv_pool<CI, CO, HH, WW, PR, MT, 8, IN_MODE>(in, w, bias, out, argmax, n, st);   \
+            return launch_conv_pool<CI, CO, HH, WW, PR, MT, NW, IN_MODE>(in, w, bias, out, argmax, n, st);  \
     }
     constexpr bool FLOAT = IN_MODE == IN_NONE;
-    PPO_CP_CASE(true, 4, 16, 84, 84, 6, 3)     // 13 rows x 84 = 69 tiles -> 23 groups of 3
-    PPO_CP_CASE(true, 5, 16, 84, 84, 6, 3)
-    PPO_CP_CASE(true, 3, 16, 64, 64, 8, 3)     // 17 rows x 64 = 68 tiles
-    PPO_CP_CASE(true, 4, 16, 64, 64, 8, 3)
-    PPO_CP_CASE(FLOAT, 16, 32, 42, 42, 3, 3)   // 7 rows x 42 = 19 tiles -> 7 groups
-    PPO_CP_CASE(FLOAT, 16, 32, 32, 32, 4, 3)   // 9 rows x 32 = 18 tiles -> 6 groups
-    PPO_CP_CASE(FLOAT, 32, 32, 21, 21, 6, 3)   // 13 rows x 21 = 18 tiles
-    PPO_CP_CASE(FLOAT, 32, 32, 16, 16, 8, 3)   // 17 rows x 16 = 17 tiles
+#ifndef PPO_CP_PR84  // 84x84 first layer: pooled rows per item / pixel tiles per wave group
+#define PPO_CP_PR84 3   // 7 rows x 84 = 37 tiles -> 8 groups of 5; 51 KB of LDS: three workgroups per CU
+#define PPO_CP_MT84 5
+#endif
+#ifndef PPO_CP_PR42
+#define PPO_CP_PR42 3   // 7 rows x 42 = 19 tiles -> 7 groups of 3
+#define PPO_CP_MT42 3
+#endif
+#ifndef PPO_CP_PR21
+#define PPO_CP_PR21 6   // 13 rows x 21 = 18 tiles -> 6 groups of 3
+#define PPO_CP_MT21 3
+#define PPO_CP_NW21 8
+#endif
+    PPO_CP_CASE(true, 4, 16, 84, 84, PPO_CP_PR84, PPO_CP_MT84, 8)
+    PPO_CP_CASE(true, 5, 16, 84, 84, PPO_CP_PR84, PPO_CP_MT84, 8)
+    PPO_CP_CASE(true, 3, 16, 64, 64, 4, 5, 8)     // 9 rows x 64 = 36 tiles -> 8 groups of 5 (as the 84x84 case)
+    PPO_CP_CASE(true, 4, 16, 64, 64, 4, 5, 8)
+    PPO_CP_CASE(FLOAT, 16, 32, 42, 42, PPO_CP_PR42, PPO_CP_MT42, 8)
+    PPO_CP_CASE(FLOAT, 16, 32, 32, 32, 4, 3, 8)   // 9 rows x 32 = 18 tiles -> 6 groups
+    PPO_CP_CASE(FLOAT, 32, 32, 21, 21, PPO_CP_PR21, PPO_CP_MT21, PPO_CP_NW21)
+    PPO_CP_CASE(FLOAT, 32, 32, 16, 16, 8, 3, 8)   // 17 rows x 16 = 17 tiles
 #undef PPO_CP_CASE
     return fail(PPO_E_INVALID, "conv3x3_pool: unsupported geometry cin=%d cout=%d h=%d w=%d in_mode=%d", cin, cout, h,
                 w_, IN_MODE);
