@@ -10,9 +10,12 @@
 // rl/impala.py:73-78 store pre-activations; ReLU is applied when the operand is read), or
 // uint8 -> x/255 (rl/models.py:842-848).
 //
-// Mapping: a 512-thread workgroup (8 waves) walks (image, band of TR output rows) items for all
-// output channels.  The input band (+1-pixel halo, zero padded) sits in LDS as planar
-// [ci][row][col] (plane stride = 16 mod 32 banks); the weights live in REGISTERS for the whole
+// Mapping: a workgroup of 8 (16-channel layers) or 4 (32-channel layers) waves walks (image, band of TR
+// output rows) items for all output channels.  The input band sits in LDS as planar [ci][row][col] with one
+// halo ROW above and below (zero outside the image) and NO halo columns: rows keep the image's row stride,
+// so a channel's band is one contiguous run that 16-byte LDS-DMA requests move, and the x-1 / x+1 taps at
+// the image edge are zeroed by the med3 that also applies ReLU-on-read (plane stride = 16 mod 32 banks).
+// The weights live in REGISTERS for the whole
 // kernel (each lane's A-operand slice wa[NT][K/4], loaded once: the filter bank is at most 36 KB and
 // every wave needs all of it for every item), as does the bias.  GEMM view: M = output channel
 // (MFMA "i"), N = pixel (MFMA "j"), K = 9*CIN with k = tap*CINP + ci.
