@@ -646,6 +646,11 @@ class Runner:
         return out
 
     # ------------------------------------------------------------------ checkpoints (rl/rollout.py:394-517)
+    def get_checkpoints(self, path):
+        """[(epoch_M, filename)] newest first (rl/rollout.py:460-470)."""
+        from .ppo import get_checkpoints
+        return get_checkpoints(path)
+
     def save_checkpoint(self, filename, step, disable_log=False, disable_replay=False, disable_env_state=False,
                         disable_optimizer=False):
         """Model under the reference's state_dict names, optimiser states, counters, env / wrapper state;
