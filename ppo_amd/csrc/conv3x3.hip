@@ -267,35 +267,96 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             // the operands of step s+PF are requested before the MFMAs of step s issue, and a
             // sched_barrier per step keeps the compiler from re-batching the reads (left alone it either
             // waits on each step's reads right before its MFMAs, or hoists all of them and spills).
-            constexpr int PF = 2;
-            float b[PF + 1][MT];
-            auto load_step = [&](int s, float (&bb)[MT]) {
-                const int tap = s / (C::CINP / 4);
-                const int cs = s % (C::CINP / 4);
-                const int tap_off = (tap / 3) * W + (tap % 3);
+            if constexpr (!TRANSPOSED) {
+                // Forward: steps go through the pipeline in blocks of SB: [wait for block j's operands, requested
+                // a whole block of MFMAs ago] -> [their ReLU / edge-mask med3s] -> [request block j+1] -> [MFMAs
+                // of block j].  At the wait only block j's reads are outstanding, so the compiler's conservative
+                // lgkmcnt(0) is exact, and no MFMA waits on a med3 issued just before it.  Measured: forward
+                // 0.559 -> 0.537 ms per 256 batch; the transposed (backward-data) kernels, whose epilogue
+                // prefetches compete for the same counters, were 5 % slower with it and keep the per-step form.
+                constexpr int SB = (MT * C::NT >= 4) ? 2 : 4;
+                constexpr int NB = (KS + SB - 1) / SB;
+                float raw[2][SB][MT];
+                auto load_block = [&](int j, float (&r)[SB][MT]) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) bb[m] = smem[base[m] + cs * 4 * C::PLANE + tap_off];
-            };
+                    for (int u = 0; u < SB; ++u) {
+                        const int s = j * SB + u;
+                        if (s < KS) {
+                            const int tap = s / (C::CINP / 4);
+                            const int cs = s % (C::CINP / 4);
+                            const int tap_off = (tap / 3) * W + (tap % 3);
 #pragma unroll
-            for (int s = 0; s < PF; ++s) load_step(s, b[s]);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s + PF < KS) load_step(s + PF, b[(s + PF) % (PF + 1)]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float bv = b[s % (PF + 1)][m];
-                    // one med3 per operand: ReLU on read (pre-activation input) and/or the edge mask
-                    const int kx = (s / (C::CINP / 4)) % 3;
-                    if (kx != 1) {
-                        const float hi = kx == 0 ? hi_l[q][m] : hi_r[q][m];
-                        bv = __builtin_amdgcn_fmed3f(bv, IN_MODE == IN_RELU ? 0.f : -hi, hi);
-                    } else if (IN_MODE == IN_RELU) {
-                        bv = relu1(bv);
+                            for (int m = 0; m < MT; ++m) r[u][m] = smem[base[m] + cs * 4 * C::PLANE + tap_off];
+                        }
                     }
+                };
+                load_block(0, raw[0]);
 #pragma unroll
-                    for (int n = 0; n < C::NT; ++n) acc[n][m] = mfma16(wa[n][s], bv, acc[n][m]);
+                for (int j = 0; j < NB; ++j) {
+                    float bv[SB][MT];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int s = j * SB + u;
+                        if (s < KS) {
+                            const int kx = (s / (C::CINP / 4)) % 3;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                float x = raw[j & 1][u][m];
+                                if (kx != 1) {
+                                    const float hi = kx == 0 ? hi_l[q][m] : hi_r[q][m];
+                                    x = __builtin_amdgcn_fmed3f(x, IN_MODE == IN_RELU ? 0.f : -hi, hi);
+                                } else if (IN_MODE == IN_RELU) {
+                                    x = relu1(x);
+                                }
+                                bv[u][m] = x;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 1 < NB) load_block(j + 1, raw[(j + 1) & 1]);
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int s = j * SB + u;
+                        if (s < KS) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                for (int n = 0; n < C::NT; ++n) acc[n][m] = mfma16(wa[n][s], bv[u][m], acc[n][m]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                constexpr int PF = 2;
+                float b[PF + 1][MT];
+                auto load_step = [&](int s, float (&bb)[MT]) {
+                    const int tap = s / (C::CINP / 4);
+                    const int cs = s % (C::CINP / 4);
+                    const int tap_off = (tap / 3) * W + (tap % 3);
+    #pragma unroll
+                    for (int m = 0; m < MT; ++m) bb[m] = smem[base[m] + cs * 4 * C::PLANE + tap_off];
+                };
+    #pragma unroll
+                for (int s = 0; s < PF; ++s) load_step(s, b[s]);
+    #pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (s + PF < KS) load_step(s + PF, b[(s + PF) % (PF + 1)]);
+    #pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float bv = b[s % (PF + 1)][m];
+                        // one med3 per operand: ReLU on read (pre-activation input) and/or the edge mask
+                        const int kx = (s / (C::CINP / 4)) % 3;
+                        if (kx != 1) {
+                            const float hi = kx == 0 ? hi_l[q][m] : hi_r[q][m];
+                            bv = __builtin_amdgcn_fmed3f(bv, IN_MODE == IN_RELU ? 0.f : -hi, hi);
+                        } else if (IN_MODE == IN_RELU) {
+                            bv = relu1(bv);
+                        }
+    #pragma unroll
+                        for (int n = 0; n < C::NT; ++n) acc[n][m] = mfma16(wa[n][s], bv, acc[n][m]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             PPO_STAMP(t_g2)
             PPO_STAMP_ADD(2, t_g2, t_g1)  // K loop
