@@ -101,9 +101,21 @@ def check(rc: int, what: str) -> None:
         raise PpoAmdError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
+_raw_stream = None
+
+
 def current_stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device.  Called once per kernel launch (tens
+    of thousands of times per second), so it goes through torch's C accessor when there is one."""
+    global _raw_stream
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        fast = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if fast is not None:
+            _raw_stream = lambda: fast(torch.cuda.current_device())  # noqa: E731
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    return _raw_stream()
 
 
 def require_gpu():

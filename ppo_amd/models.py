@@ -144,6 +144,11 @@ def init_impala_parameters(spec: ImpalaSpec, n_actions: int, vh: int, head_scale
     return init_parameters(spec, n_actions, vh, head_scale, head_bias)
 
 
+def plan_input_keys(kind):
+    """Entries of encode()'s result that alias the input tensor."""
+    return ("x", "in0") if kind == "impala" else ("x",)
+
+
 class AdamState:
     """Adam moments + step count over a net's flat parameter buffer."""
 
@@ -203,6 +208,8 @@ class DualHeadNet:
         self.nh = self.col_tvf + self.K * self.vh
         self._build_parameters(head_scale)
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._rec = None   # launch recorder (see encode)
+        self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self._adam_step = 0
         self.exp_avg = None
         self.exp_avg_sq = None
@@ -284,7 +291,10 @@ class DualHeadNet:
         return self._buf(name, ((nbytes + 3) // 4,), torch.float32)
 
     def _call(self, fn_name, *args):
-        rc = getattr(self.lib, fn_name)(*args, _lib.current_stream())
+        fn = getattr(self.lib, fn_name)
+        if self._rec is not None:
+            self._rec.append((fn, fn_name, args))
+        rc = fn(*args, _lib.current_stream())
         if rc != 0:
             _lib.check(rc, fn_name)
 
@@ -324,12 +334,38 @@ class DualHeadNet:
             raise ValueError(f"expected input [B, {sp.input_dims}], got {tuple(x.shape)}")
         if x.dtype not in (torch.uint8, torch.float32) or not x.is_contiguous() or x.device != self.device:
             raise ValueError("input must be a contiguous uint8/float32 tensor on the model's device")
-        acts = self._encode_mlp(x, train, tag) if self.encoder_kind == "mlp" else self._encode_impala(x, train, tag)
-        if self.encoder_activation_fn == "tanh":
-            h = acts["h"]
-            hact = self._buf(tag + "hact", tuple(h.shape))
-            self._call("ppo_tanh_forward_f32", _p(h), _p(hact), h.numel())
-            acts["hact"] = hact
+        # Inference forwards (the rollout: 2 x 257 per iteration, with the host on the critical path) replay a
+        # recorded launch list: every pointer and size of a (tag, batch) forward is fixed — scratch buffers
+        # persist, parameters are views of one flat buffer — except the input, which is patched in.  That cuts
+        # the per-launch Python work to the ctypes call itself.
+        key = (tag, x.shape[0], x.dtype)
+        plan = None if train else self._plans.get(key)
+        if plan is not None:
+            calls, acts, x_slots = plan
+            st, xp = _lib.current_stream(), x.data_ptr()
+            for k, (fn, fn_name, args) in enumerate(calls):
+                rc = fn(xp, *args[1:], st) if k in x_slots else fn(*args, st)
+                if rc != 0:
+                    _lib.check(rc, fn_name)
+            out = dict(acts)
+            for name in plan_input_keys(self.encoder_kind):
+                out[name] = x
+            return out
+        if not train:
+            self._rec = []
+        try:
+            acts = self._encode_mlp(x, train, tag) if self.encoder_kind == "mlp" else self._encode_impala(x, train, tag)
+            if self.encoder_activation_fn == "tanh":
+                h = acts["h"]
+                hact = self._buf(tag + "hact", tuple(h.shape))
+                self._call("ppo_tanh_forward_f32", _p(h), _p(hact), h.numel())
+                acts["hact"] = hact
+            if not train:
+                xp = x.data_ptr()
+                x_slots = frozenset(k for k, (_f, _n, a) in enumerate(self._rec) if a and a[0] == xp)
+                self._plans[key] = (self._rec, {k: v for k, v in acts.items() if v is not x}, x_slots)
+        finally:
+            self._rec = None
         return acts
 
     def _encode_mlp(self, x, train, tag):

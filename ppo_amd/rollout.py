@@ -244,10 +244,14 @@ class Runner:
         final = t >= self.N
         seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + self.rank
         counter = ((self._sample_calls + t) * A + lo) * nA
-        values = None if self.dual else _p(self.value[t, lo:hi])
+        first = t * A + lo  # first (t, env) element of this group's rows: pointer arithmetic, no tensor slicing
 
         def row(buf):
-            return None if final else _p(buf[t, lo:hi])
+            if final:
+                return None
+            return buf.data_ptr() + first * buf.stride(1) * buf.element_size()
+
+        values = None if self.dual else self.value.data_ptr() + first * self.value.stride(1) * 4
 
         if self.action_dist == "discrete":
             self._call("ppo_policy_act_f32", _p(hp), B, pol.nh, nA, 1.0, None, seed & (2**64 - 1), counter, 0,
@@ -314,20 +318,22 @@ class Runner:
             # H2D of group i's observations (pinned -> HBM) on the copy stream, so it runs on a DMA engine
             # under the other group's policy step; then policy + sampling, actions D2H; all async
             lo, hi = bounds[i], bounds[i + 1]
-            with torch.cuda.stream(copy_stream):
-                if graphs[i] is not None:  # the graph reads a fixed staging buffer; the rollout row is a D2D copy of it
-                    graphs[i][1].copy_(parts[i].obs_t, non_blocking=True)
-                    copy_events[i].record()
-                    self.all_obs[t, lo:hi].copy_(graphs[i][1], non_blocking=True)
-                else:
-                    self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
-                    copy_events[i].record()
-            with torch.cuda.stream(streams[i]):
-                streams[i].wait_event(copy_events[i])
-                self._policy_step(t, lo, hi, tag=f"i{i}" if P > 1 else "i", graph=graphs[i])
-                if t < N:
-                    self._actions_host[lo:hi].copy_(self.actions[t, lo:hi], non_blocking=True)
-                    events[i].record()
+            # (set_stream rather than the `with torch.cuda.stream` context: this runs 2 x 257 times per rollout
+            # and the host is on the critical path; the main stream is restored in the finally below)
+            torch.cuda.set_stream(copy_stream)
+            if graphs[i] is not None:  # the graph reads a fixed staging buffer; the rollout row is a D2D copy of it
+                graphs[i][1].copy_(parts[i].obs_t, non_blocking=True)
+                copy_events[i].record()
+                self.all_obs[t, lo:hi].copy_(graphs[i][1], non_blocking=True)
+            else:
+                self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
+                copy_events[i].record()
+            torch.cuda.set_stream(streams[i])
+            streams[i].wait_event(copy_events[i])
+            self._policy_step(t, lo, hi, tag=tags[i], graph=graphs[i])
+            if t < N:
+                host_rows[i].copy_(self.actions[t, lo:hi], non_blocking=True)
+                events[i].record()
 
         def step_envs(i, t):
             # the one host wait of group i's step: its actions have landed; then step it on host cores
@@ -337,12 +343,17 @@ class Runner:
             _, ep_len, ep_score = parts[i].last_episode_stats
             self._log_finished(done_np[t, lo:hi].astype(bool), ep_len, ep_score)
 
-        for t in range(N + 1):
-            for i in range(P):
-                enqueue(i, t)  # needs obs(i, t): group i was stepped for t-1 below
-                j, tj = (i + 1) % P, (t if i + 1 == P else t - 1)
-                if 0 <= tj < N:
-                    step_envs(j, tj)  # overlaps the GPU work just queued for group i
+        tags = [f"i{i}" if P > 1 else "i" for i in range(P)]
+        host_rows = [self._actions_host[bounds[i]:bounds[i + 1]] for i in range(P)]
+        try:
+            for t in range(N + 1):
+                for i in range(P):
+                    enqueue(i, t)  # needs obs(i, t): group i was stepped for t-1 below
+                    j, tj = (i + 1) % P, (t if i + 1 == P else t - 1)
+                    if 0 <= tj < N:
+                        step_envs(j, tj)  # overlaps the GPU work just queued for group i
+        finally:
+            torch.cuda.set_stream(main)
         for s_ in streams:
             if s_ is not main:
                 main.wait_stream(s_)
