@@ -53,6 +53,37 @@ def test_cartpole_mlp_learns_through_the_process_pool():
         r.vec_env.close()
 
 
+def test_cartpole_learns_with_the_dual_architecture():
+    """DNA end to end: policy from policy_net, advantages from value_net's estimates, value phase on value_net,
+    distillation back into policy_net — PPO still has to learn CartPole with all of that in the loop."""
+    args.setup(["--agents=16", "--n_steps=64", "--model_architecture=dual", "--model_encoder=mlp",
+                "--model_hidden_units=64", "--env_type=classic", "--env_name=CartPole", "--seed=4", "--device=cuda",
+                "--policy_opt_mini_batch_size=256", "--policy_opt_epochs=4", "--policy_opt_lr=0.001",
+                "--value_opt_mini_batch_size=256", "--value_opt_epochs=2", "--value_opt_lr=0.001",
+                "--distil_opt_mini_batch_size=256", "--distil_opt_epochs=1", "--workers=4", "--gamma=0.99",
+                "--disable_logging=True"])
+    torch.manual_seed(4)
+    np.random.seed(4)
+    model = models.TVFModel("mlp", input_dims=(4,), actions=2, device="cuda", architecture="dual", hidden_units=64,
+                            head_scale=0.1, head_bias=True)
+    r = rollout.Runner(model, logger.Logger(quiet=True))
+    r.vec_env = envs.create_envs_classic()
+    try:
+        r.reset()
+        lengths = []
+        for _ in range(30):
+            r.generate_rollout()
+            r.calculate_returns()
+            r.train()
+            lengths.append(r.N * r.A / max(int(r.terminals.sum()), 1))
+        stats = r.fetch_stats()
+        assert np.isfinite(stats["loss_distil"]) and np.isfinite(stats["loss_value"])
+        early, late = np.mean(lengths[:3]), np.mean(lengths[-3:])
+        assert early < 40 and late > 2.5 * early, lengths
+    finally:
+        r.vec_env.close()
+
+
 def test_dual_architecture_runs_policy_value_distil_phases():
     args.setup(["--agents=16", "--n_steps=16", "--model_architecture=dual", "--model_encoder=impala",
                 "--env_type=synthetic", "--env_embed_time=False", "--seed=5", "--device=cuda",
