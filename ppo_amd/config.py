@@ -152,6 +152,8 @@ class Config:
         self.grad_clip_mode = "global_norm"  # :776
         self.advantage_epsilon = 1e-8  # :792
         self.advantage_clipping = None
+        self.ppo_epsilon_anneal = False
+        self.anneal_target_epoch = None
         self.max_micro_batch_size = 512  # :760
         self.device = "cpu"            # :731 (the reference default; this build requires a GPU)
         self.upload_batch = False      # :732
@@ -208,6 +210,8 @@ class Config:
         a("--grad_clip_mode", type=str, default=self.grad_clip_mode, help="[off|global_norm]")
         a("--advantage_epsilon", type=float, default=self.advantage_epsilon)
         a("--advantage_clipping", type=float, default=None)
+        a("--ppo_epsilon_anneal", type=str2bool, nargs="?", const=True, default=False)
+        a("--anneal_target_epoch", type=float, default=None)
         a("--max_micro_batch_size", type=int, default=self.max_micro_batch_size)
         a("--device", type=str, default=self.device)
         a("--upload_batch", type=str2bool, nargs="?", const=True, default=self.upload_batch)

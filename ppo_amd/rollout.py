@@ -19,6 +19,7 @@ What changed relative to the reference, and why (MI355X-first):
     RCCL all-reduce of the flat gradient per optimiser step and one of the three advantage moments per
     batch, so an N-GPU run equals a 1-GPU run with N*A envs up to minibatch composition.
 """
+import math
 import os
 
 import numpy as np
@@ -161,9 +162,42 @@ class Runner:
     def prev_obs(self):
         return self.all_obs[:-1]
 
+    def anneal(self, x, mode: str = "linear"):
+        """rl/rollout.py:331-355: scale x by the remaining (linear) or elapsed (linear_inc / quad_inc) fraction
+        of training, measured in env steps over `anneal_target_epoch or epochs` million."""
+        assert mode in ["off", "linear", "cos", "cos_linear", "linear_inc", "quad_inc"], f"invalid mode {mode}"
+        frac = self.step / ((args.anneal_target_epoch or args.epochs) * 1e6)
+        factor = 1.0
+        if mode in ("linear", "cos_linear"):
+            factor *= float(np.clip(1 - frac, 0, 1))
+        if mode == "linear_inc":
+            factor *= float(np.clip(frac, 0, 1))
+        if mode == "quad_inc":
+            factor *= float(np.clip(frac ** 2, 0, 1))
+        if mode in ("cos", "cos_linear"):
+            factor *= (1 + math.cos(math.pi * 2 * self.step / 20e6)) / 2  # the reference's fixed 20M-step period (:345)
+        return x * factor
+
+    def _lr(self, cfg):
+        """Learning rate of one optimiser group, annealed linearly to 0 when its lr_anneal flag is set
+        (rl/rollout.py:357-392)."""
+        return self.anneal(cfg.lr, mode="linear" if cfg.lr_anneal else "off")
+
+    @property
+    def policy_lr(self):
+        return self._lr(args.policy_opt)
+
+    @property
+    def value_lr(self):
+        return self._lr(args.value_opt)
+
+    @property
+    def distil_lr(self):
+        return self._lr(args.distil_opt)
+
     @property
     def ppo_epsilon(self):
-        return args.ppo_epsilon
+        return self.anneal(args.ppo_epsilon, mode="linear" if args.ppo_epsilon_anneal else "off")
 
     @property
     def current_entropy_bonus(self):
@@ -421,7 +455,7 @@ class Runner:
         opt = optimizer or self.policy_optimizer
         net, cfg = opt.net, opt.cfg
         parallel.allreduce_sum_(net.grad)
-        net.adam_step(lr=cfg.lr, beta1=cfg.adam_beta1, beta2=cfg.adam_beta2, eps=cfg.adam_epsilon,
+        net.adam_step(lr=self._lr(cfg), beta1=cfg.adam_beta1, beta2=cfg.adam_beta2, eps=cfg.adam_epsilon,
                       max_grad_norm=args.max_grad_norm if args.grad_clip_mode == "global_norm" else 0.0,
                       grad_div=float(self.world), grad_norm_out=self._grad_norm, state=opt.state)
         return self._grad_norm

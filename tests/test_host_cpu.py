@@ -165,3 +165,29 @@ def test_data_parallel_helpers_two_ranks_gloo(hip_lib, tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_annealing_follows_the_reference_schedule():
+    """Runner.anneal / learning-rate properties (rl/rollout.py:331-392) — pure host arithmetic, checked on a
+    stand-in object so no GPU is needed."""
+    import math
+    import types
+
+    from ppo_amd import rollout
+    from ppo_amd.config import args
+    args.setup(["--epochs=10", "--policy_opt_lr=0.001", "--policy_opt_lr_anneal=True", "--ppo_epsilon_anneal=True"])
+    r = types.SimpleNamespace(step=2.5e6)
+    anneal = lambda x, mode="linear": rollout.Runner.anneal(r, x, mode)  # noqa: E731
+    r.anneal = anneal
+    assert anneal(2.0, "off") == 2.0
+    assert abs(anneal(2.0, "linear") - 1.5) < 1e-12 and abs(anneal(2.0, "linear_inc") - 0.5) < 1e-12
+    assert abs(anneal(2.0, "quad_inc") - 2.0 * 0.0625) < 1e-12
+    assert abs(anneal(1.0, "cos") - (1 + math.cos(math.pi * 2 * 2.5e6 / 20e6)) / 2) < 1e-12
+    assert abs(rollout.Runner._lr(r, args.policy_opt) - 0.00075) < 1e-12
+    assert rollout.Runner._lr(r, args.value_opt) == args.value_opt.lr  # not annealed
+    r.step = 20e6  # past the end: clipped at 0
+    assert anneal(2.0, "linear") == 0.0 and anneal(2.0, "linear_inc") == 2.0
+    args.setup(["--epochs=10", "--anneal_target_epoch=5"])
+    r.step = 2.5e6
+    assert abs(anneal(2.0, "linear") - 1.0) < 1e-12
+    args.setup([])
