@@ -153,6 +153,10 @@ class Config:
         self.advantage_epsilon = 1e-8  # :792
         self.advantage_clipping = None
         self.ppo_epsilon_anneal = False
+        self.entropy_scaling = "off"           # [off|average|uniform]
+        self.entropy_scaling_base_actions = 18
+        self.entropy_anneal = False
+        self.advantage_epsilon_anneal_factor = 0.0
         self.anneal_target_epoch = None
         self.max_micro_batch_size = 512  # :760
         self.device = "cpu"            # :731 (the reference default; this build requires a GPU)
@@ -211,6 +215,10 @@ class Config:
         a("--advantage_epsilon", type=float, default=self.advantage_epsilon)
         a("--advantage_clipping", type=float, default=None)
         a("--ppo_epsilon_anneal", type=str2bool, nargs="?", const=True, default=False)
+        a("--entropy_scaling", type=str, default="off", help="[off|average|uniform]")
+        a("--entropy_scaling_base_actions", type=int, default=18)
+        a("--entropy_anneal", type=str2bool, nargs="?", const=True, default=False)
+        a("--advantage_epsilon_anneal_factor", type=float, default=0.0)
         a("--anneal_target_epoch", type=float, default=None)
         a("--max_micro_batch_size", type=int, default=self.max_micro_batch_size)
         a("--device", type=str, default=self.device)

@@ -201,7 +201,25 @@ class Runner:
 
     @property
     def current_entropy_bonus(self):
-        return args.entropy_bonus
+        """rl/rollout.py:1568-1587: optional rescaling by the size of the action set, optional annealing."""
+        if args.entropy_scaling == "off":
+            bonus = args.entropy_bonus
+        elif args.entropy_scaling == "average":
+            assert args.entropy_scaling_base_actions > 0
+            bonus = args.entropy_bonus * (args.entropy_scaling_base_actions / self.model.actions)
+        elif args.entropy_scaling == "uniform":
+            assert args.entropy_scaling_base_actions > 0
+            bonus = args.entropy_bonus * (math.log(args.entropy_scaling_base_actions) / math.log(self.model.actions))
+        else:
+            raise ValueError(f"Invalid entropy_scaling method {args.entropy_scaling}.")
+        return self.anneal(bonus) if args.entropy_anneal else bonus
+
+    @property
+    def current_advantage_epsilon(self):
+        """rl/rollout.py:1589-1594."""
+        if args.advantage_epsilon_anneal_factor > 0:
+            return args.advantage_epsilon * max((1 / args.advantage_epsilon_anneal_factor) ** (self.step / 10e6), 1e-8)
+        return args.advantage_epsilon
 
     @property
     def value_heads(self):
@@ -445,7 +463,7 @@ class Runner:
         n = self.N * self.A
         self._call("ppo_moments_f64", _p(self.advantage), n, _p(self._moments), _p(self._moments_ws))
         parallel.allreduce_sum_(self._moments)
-        self._call("ppo_normalize_f32", _p(self.advantage), n, _p(self._moments), float(args.advantage_epsilon),
+        self._call("ppo_normalize_f32", _p(self.advantage), n, _p(self._moments), float(self.current_advantage_epsilon),
                    _p(self.norm_advantage), _p(self._mean_std))
         if args.advantage_clipping is not None:
             self.norm_advantage.clamp_(-args.advantage_clipping, args.advantage_clipping)
