@@ -99,6 +99,45 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
     }
 }
 
+// Even H and W (every IMPALA stack input except the odd 21x21 / 11x11 ones): one thread -> the 2x2 input block
+// (rows 2j, 2j+1; columns 2k, 2k+1).  The four windows that can select these elements are (j,k), (j,k+1),
+// (j+1,k), (j+1,k+1): 4 (argmax, gradient) pairs feed 4 outputs, where the row-pair form above reads 6.
+__global__ __launch_bounds__(256) void maxpool_bwd2x2_kernel(const float *__restrict__ dout,
+                                                             const uint8_t *__restrict__ argmax,
+                                                             float *__restrict__ din, int H, int W, int Ho, int Wo)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Ho * Wo) return;
+    const int64_t pl = blockIdx.y;
+    const int j = t / Wo;
+    const int k = t - j * Wo;
+    const float *g = dout + pl * Ho * Wo + t;
+    const uint8_t *a = argmax + pl * Ho * Wo + t;
+    const bool right = k + 1 < Wo, down = j + 1 < Ho;
+    const int t00 = a[0];
+    const float g00 = g[0];
+    const int t01 = right ? a[1] : -1;
+    const float g01 = right ? g[1] : 0.f;
+    const int t10 = down ? a[Wo] : -1;
+    const float g10 = down ? g[Wo] : 0.f;
+    const int t11 = (right && down) ? a[Wo + 1] : -1;
+    const float g11 = (right && down) ? g[Wo + 1] : 0.f;
+    // taps are ky*3+kx; summation order per element = window order (j,k), (j,k+1), (j+1,k), (j+1,k+1), the same
+    // order the row-pair kernel uses
+    const float r00 = (t00 == 4 ? g00 : 0.f);
+    float r01 = (t00 == 5 ? g00 : 0.f);
+    r01 += (t01 == 3 ? g01 : 0.f);
+    float r10 = (t00 == 7 ? g00 : 0.f);
+    r10 += (t10 == 1 ? g10 : 0.f);
+    float r11 = (t00 == 8 ? g00 : 0.f);
+    r11 += (t01 == 6 ? g01 : 0.f);
+    r11 += (t10 == 2 ? g10 : 0.f);
+    r11 += (t11 == 0 ? g11 : 0.f);
+    float *dst = din + pl * H * W + (2 * j) * W + 2 * k;
+    *reinterpret_cast<float2 *>(dst) = make_float2(r00, r01);
+    *reinterpret_cast<float2 *>(dst + W) = make_float2(r10, r11);
+}
+
 }  // namespace
 }  // namespace ppo
 
@@ -126,7 +165,10 @@ extern "C" int ppo_maxpool3x3s2_backward_f32(const float *dout, const uint8_t *a
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
     const int threads = h * ((w + 1) / 2);
     const dim3 grid((threads + 255) / 256, n * c);
-    if (w % 2 == 0 && aligned(din, 8))
+    if (w % 2 == 0 && h % 2 == 0 && aligned(din, 8))
+        hipLaunchKernelGGL(maxpool_bwd2x2_kernel, dim3((ho * wo + 255) / 256, n * c), dim3(256), 0, as_stream(stream), dout,
+                           argmax, din, h, w, ho, wo);
+    else if (w % 2 == 0 && aligned(din, 8))
         hipLaunchKernelGGL(maxpool_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), dout, argmax, din, h, w, ho, wo);
     else
         hipLaunchKernelGGL(maxpool_bwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), dout, argmax, din, h, w, ho, wo);
