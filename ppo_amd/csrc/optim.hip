@@ -14,6 +14,7 @@ namespace ppo {
 namespace {
 
 constexpr int kPartials = 256;
+__device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict__ g, int64_t n, float *__restrict__ partials)
 {
@@ -23,7 +24,15 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict
     const int64_t lo = (int64_t)blockIdx.x * chunk;
     const int64_t hi = lo + chunk < n ? lo + chunk : n;
     float acc = 0.f;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    int64_t i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {  // four independent loads in flight per thread
+        const float x0 = g[i], x1 = g[i + 256], x2 = g[i + 512], x3 = g[i + 768];
+        acc += x0 * x0;
+        acc += x1 * x1;
+        acc += x2 * x2;
+        acc += x3 * x3;
+    }
+    for (; i < hi; i += 256) {
         const float x = g[i];
         acc += x * x;
     }
@@ -45,9 +54,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
                                                    float *__restrict__ norm_out)
 {
     __shared__ float s_clip;
+    __shared__ float s_part[256];
+    // every workgroup re-reduces the partials the same way (one load per thread, then a fixed-order tree), so all
+    // of them clip by the same factor without a grid-wide exchange
+    s_part[threadIdx.x] = (int)threadIdx.x < n_partials ? partials[threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s_part[threadIdx.x] += s_part[threadIdx.x + w];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < n_partials; ++i) tot += partials[i];
+        const float tot = s_part[0];
         // gradients may still carry a 1/world_size (or micro-batch) factor: grad_div
         const float norm = sqrtf(tot) / grad_div;
         float clip = 1.f;
@@ -61,15 +78,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
     __syncthreads();
     const float gscale = s_clip;
     const float step_size = lr / bias_c1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        float mi = m[i], vi = v[i];
+    auto update = [&](float &wi, float gi, float &mi, float &vi) {
+        gi *= gscale;
         mi = mi + (gi - mi) * one_minus_beta1;           // exp_avg.lerp_(grad, 1 - beta1)
         vi = vi * beta2 + one_minus_beta2 * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
         const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
-        w[i] = w[i] - step_size * (mi / denom);
-        m[i] = mi;
-        v[i] = vi;
+        wi = wi - step_size * (mi / denom);
+    };
+    // the flat buffers are 16-byte aligned and padded to a multiple of 4 (ppo_amd/models.py); otherwise scalar
+    const bool vec = (n % 4 == 0) && aligned16(w) && aligned16(g) && aligned16(m) && aligned16(v);
+    if (vec) {
+        const int64_t n4 = n / 4;
+        float4 *w4 = reinterpret_cast<float4 *>(w), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            float4 ww = w4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+            update(ww.x, gg.x, mm.x, vv.x);
+            update(ww.y, gg.y, mm.y, vv.y);
+            update(ww.z, gg.z, mm.z, vv.z);
+            update(ww.w, gg.w, mm.w, vv.w);
+            w4[i] = ww;
+            m4[i] = mm;
+            v4[i] = vv;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            float wi = w[i], mi = m[i], vi = v[i];
+            update(wi, g[i], mi, vi);
+            w[i] = wi;
+            m[i] = mi;
+            v[i] = vi;
+        }
     }
 }
 
