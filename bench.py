@@ -135,9 +135,12 @@ def bench_scan(lib, N, A_big, A_cfg):
             go()
             ev[k + 1].record()
         torch.cuda.synchronize()
-        ms = sum(ev[k].elapsed_time(ev[k + 1]) for k in range(reps)) / reps
+        per = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))
+        ms = sum(per) / reps
         gbps = SCAN_BYTES_PER_ELEM * N * A / (ms * 1e-3) / 1e9
         out[tag] = {"N": N, "A": A, "avg_kernel_us": round(ms * 1e3, 2), "achieved_GBps": round(gbps, 1),
+                    "min_kernel_us": round(per[0] * 1e3, 2), "max_kernel_us": round(per[-1] * 1e3, 2),
+                    "launches_timed": reps,
                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
                     "kernel": "gae_columns_kernel" if A > 65536 else "gae_tiles_kernel"}
         if tag == "bandwidth":
