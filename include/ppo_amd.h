@@ -139,6 +139,25 @@ int ppo_conv3x3_backward_weight_f32(const void *in, int in_mode, const float *dy
                                     int w, int accumulate, void *stream);
 
 /*
+ * The same weight gradient in two steps, for callers that batch the reductions of many layers into one launch
+ * (a backward pass: 15 convolutions): *_slabs_f32 runs the MFMA kernel only and leaves its per-workgroup partial
+ * slabs in `workspace` (which the caller keeps until the reduction), writing their number to *n_slabs (host);
+ * ppo_conv3x3_wgrad_reduce_f32 then sums the slabs of up to 32 layers (`jobs`: HOST array) in fixed order into
+ * dweight / dbias.  Results are bit-identical to ppo_conv3x3_backward_weight_f32.
+ */
+typedef struct ppo_wgrad_job {
+    const float *slabs; /* workspace of the matching *_slabs_f32 call */
+    float *dweight;     /* [cout, cin, 3, 3] */
+    float *dbias;       /* [cout] or NULL */
+    int n_slabs, cin, cout;
+    int accumulate;     /* != 0: add into dweight / dbias */
+} ppo_wgrad_job;
+int ppo_conv3x3_backward_weight_slabs_f32(const void *in, int in_mode, const float *dy, void *workspace,
+                                          size_t workspace_bytes, int n, int cin, int cout, int h, int w,
+                                          int *n_slabs, void *stream);
+int ppo_conv3x3_wgrad_reduce_f32(const ppo_wgrad_job *jobs, int n_jobs, void *stream);
+
+/*
  * 3x3 / stride 2 / pad 1 max pooling (F.max_pool2d, rl/impala.py:105): [n,c,h,w] -> [n,c,(h+1)/2,(w+1)/2].
  * argmax (nullable uint8 [n,c,ho,wo]) records the winning window tap for the backward pass.
  * Backward: din[n,c,h,w] = sum of dout over the windows whose argmax is this element.

@@ -57,6 +57,8 @@ SIGNATURES = {
     "ppo_synth_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ppo_conv3x3_pool_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_backward_weight_slabs_f32": (_i, [_vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ppo_conv3x3_wgrad_reduce_f32": (_i, [_vp, _i, _vp]),
     "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),
     "ppo_tanh_backward_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "ppo_value_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
@@ -66,6 +68,12 @@ SIGNATURES = {
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
 }
+
+class WgradJob(ctypes.Structure):
+    """ppo_wgrad_job (include/ppo_amd.h)."""
+    _fields_ = [("slabs", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("n_slabs", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("accumulate", ctypes.c_int)]
+
 
 _lock = threading.Lock()
 _lib = None

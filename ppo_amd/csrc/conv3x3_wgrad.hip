@@ -322,9 +322,78 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *
 
 constexpr int kWgradMaxSlabs = 512;
 
+// The same reduction for up to kMaxJobs layers in one launch (blockIdx.y = layer): a backward pass defers its
+// 15 slab reductions to one launch at the end instead of 15 small ones between the wgrad kernels.
+constexpr int kMaxJobs = 32;
+struct ReduceJobs {
+    ppo_wgrad_job j[kMaxJobs];
+};
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_jobs_kernel(ReduceJobs jobs)
+{
+    __shared__ float4 s[256];
+    const ppo_wgrad_job &job = jobs.j[blockIdx.y];
+    const int cout = job.cout, cin = job.cin, n_slabs = job.n_slabs, accumulate = job.accumulate;
+    const int cinp = (cin + 3) / 4 * 4;
+    const int jp = ((9 * cinp + 1) + 15) / 16 * 16;
+    const int q4 = jp / 4;
+    if ((int)blockIdx.x * 16 >= cout * q4) return;  // this layer needs fewer blocks than the widest one
+    const int idx = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int part = threadIdx.x >> 4;
+    const bool live = idx < cout * q4;
+    const int co = live ? idx / q4 : 0;
+    const int j0 = live ? (idx % q4) * 4 : 0;
+    const size_t stride = (size_t)cout * jp;
+    const float *p = job.slabs + (size_t)co * jp + j0;
+    const int per = (n_slabs + 15) / 16;
+    const int lo = part * per;
+    const int hi = lo + per < n_slabs ? lo + per : n_slabs;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (live) {
+        int q = lo;
+        for (; q + 2 <= hi; q += 2) {
+            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
+            const float4 b = *reinterpret_cast<const float4 *>(p + (size_t)(q + 1) * stride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        for (; q < hi; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    s[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (part == 0 && live) {
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  // fixed order over the slab partitions (same order as the single-layer kernel)
+            const float4 a = s[q * 16 + threadIdx.x];
+            sum[0] += a.x;
+            sum[1] += a.y;
+            sum[2] += a.z;
+            sum[3] += a.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            if (j == 9 * cinp) {
+                if (job.dbias) job.dbias[co] = accumulate ? job.dbias[co] + sum[e] : sum[e];
+            } else if (j < 9 * cinp) {
+                const int tap = j / cinp;
+                const int ci = j % cinp;
+                if (ci < cin) {
+                    float *d = job.dweight + ((size_t)co * cin + ci) * 9 + tap;
+                    *d = accumulate ? *d + sum[e] : sum[e];
+                }
+            }
+        }
+    }
+}
+
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
 int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *workspace, size_t workspace_bytes,
-                 int n_images, int accumulate, hipStream_t st)
+                 int n_images, int accumulate, hipStream_t st, int *n_slabs_out = nullptr)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
     auto kern = conv3x3_wgrad_kernel<CIN, COUT, H, W, TR, IN_MODE>;
@@ -349,6 +418,10 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWgradWaves * 64), C::LDS_BYTES, st, in, dy, workspace, n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
+    if (n_slabs_out) {  // slabs only: the caller reduces later (ppo_conv3x3_wgrad_reduce_f32)
+        *n_slabs_out = grid;
+        return PPO_OK;
+    }
     const int total = COUT * (C::JP / 4);  // one thread quad-group per 4 consecutive j
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, st, workspace, grid, COUT,
                        CIN, C::CINP, C::JP, dw, db, accumulate);
@@ -357,12 +430,12 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
 
 template <int IN_MODE>
 int dispatch_wgrad(int cin, int cout, int h, int w_, const void *in, const float *dy, float *dw, float *db,
-                   float *ws, size_t ws_bytes, int n, int accumulate, hipStream_t st)
+                   float *ws, size_t ws_bytes, int n, int accumulate, hipStream_t st, int *n_slabs_out = nullptr)
 {
 #define PPO_WGRAD_CASE(ALLOWED, CI, CO, HH, WW, TR)                                                  \
     if constexpr (ALLOWED) {                                                                         \
         if (cin == CI && cout == CO && h == HH && w_ == WW)                                          \
-            return launch_wgrad<CI, CO, HH, WW, TR, IN_MODE>(in, dy, dw, db, ws, ws_bytes, n, accumulate, st); \
+            return launch_wgrad<CI, CO, HH, WW, TR, IN_MODE>(in, dy, dw, db, ws, ws_bytes, n, accumulate, st, n_slabs_out); \
     }
     constexpr bool FIRST = IN_MODE != IN_RELU;
     constexpr bool UP = IN_MODE == IN_NONE;
@@ -411,4 +484,43 @@ extern "C" int ppo_conv3x3_backward_weight_f32(const void *in, int in_mode, cons
         case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, in, dy, dweight, dbias, ws, workspace_bytes, n, accumulate, st);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_f32: unknown in_mode %d", in_mode);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_slabs_f32(const void *in, int in_mode, const float *dy, void *workspace,
+                                                     size_t workspace_bytes, int n, int cin, int cout, int h, int w,
+                                                     int *n_slabs, void *stream)
+{
+    using namespace ppo;
+    if (n <= 0) return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_f32: n must be positive");
+    if (!in || !dy || !workspace || !n_slabs) return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_f32: null pointer");
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(workspace);
+    switch (in_mode) {
+        case IN_NONE: return dispatch_wgrad<IN_NONE>(cin, cout, h, w, in, dy, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs);
+        case IN_RELU: return dispatch_wgrad<IN_RELU>(cin, cout, h, w, in, dy, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs);
+        case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, in, dy, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs);
+    }
+    return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_f32: unknown in_mode %d", in_mode);
+}
+
+extern "C" int ppo_conv3x3_wgrad_reduce_f32(const ppo_wgrad_job *jobs, int n_jobs, void *stream)
+{
+    using namespace ppo;
+    if (n_jobs < 0 || n_jobs > kMaxJobs) return fail(PPO_E_INVALID, "ppo_conv3x3_wgrad_reduce_f32: 0..%d jobs per call", kMaxJobs);
+    if (n_jobs == 0) return PPO_OK;
+    if (!jobs) return fail(PPO_E_INVALID, "ppo_conv3x3_wgrad_reduce_f32: null jobs");
+    ReduceJobs rj;
+    int max_blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const ppo_wgrad_job &j = jobs[i];
+        if (!j.slabs || !j.dweight || j.n_slabs <= 0 || j.cin <= 0 || j.cout <= 0 || j.cout % 16)
+            return fail(PPO_E_INVALID, "ppo_conv3x3_wgrad_reduce_f32: bad job %d", i);
+        rj.j[i] = j;
+        const int cinp = (j.cin + 3) / 4 * 4;
+        const int jp = ((9 * cinp + 1) + 15) / 16 * 16;
+        const int blocks = (j.cout * (jp / 4) + 15) / 16;
+        max_blocks = blocks > max_blocks ? blocks : max_blocks;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_jobs_kernel, dim3(max_blocks, n_jobs), dim3(256), 0, as_stream(stream), rj);
+    return check_launch("conv3x3_wgrad_reduce_jobs_kernel");
 }

@@ -11,6 +11,7 @@ and the RCCL gradient all-reduce are single launches) and are exposed under the 
 torch is used for device memory, views and (on the CPU, at construction only) the reference's
 parameter initialisers; no torch operator is on the forward/backward path.
 """
+import ctypes
 import math
 import os
 from collections import OrderedDict
@@ -28,6 +29,8 @@ _ALIGN = 4  # floats: every parameter starts on a 16-byte boundary
 FUSE_POOL_STACKS = int(os.environ.get("PPO_AMD_FUSE_POOL", "7"))
 # weight-gradient kernels on a second stream, overlapping the backward-data chain (0 = one stream)
 WGRAD_SIDE_STREAM = int(os.environ.get("PPO_AMD_WGRAD_STREAM", "1"))
+# the slab reductions of all convolution layers in one launch at the end of the backward pass (0 = one per layer)
+WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -524,20 +527,31 @@ class DualHeadNet:
         side = self._wgrad_side_stream() if WGRAD_SIDE_STREAM else None
         n_wgrad = [0]
 
+        jobs = []  # deferred slab reductions: one launch for all layers at the end of the pass
+
         def wgrad(x, mode, dy, wname, n, cin, cout, hh, ww):
             nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
-            ws = self._ws("wgrad_ws", nbytes)
-            args_ = ("ppo_conv3x3_backward_weight_f32", _p(x), mode, _p(dy), _p(self.grads[wname + ".weight"]),
-                     _p(self.grads[wname + ".bias"]), _p(ws), nbytes, n, cin, cout, hh, ww, 0)
+            if WGRAD_BATCH_REDUCE:
+                ws = self._ws("wgrad_ws_" + wname, nbytes)  # per layer: the slabs live until the batched reduction
+                n_slabs = ctypes.c_int(0)
+                args_ = ("ppo_conv3x3_backward_weight_slabs_f32", _p(x), mode, _p(dy), _p(ws), nbytes, n, cin, cout,
+                         hh, ww, ctypes.addressof(n_slabs))
+            else:
+                ws = self._ws("wgrad_ws", nbytes)
+                args_ = ("ppo_conv3x3_backward_weight_f32", _p(x), mode, _p(dy), _p(self.grads[wname + ".weight"]),
+                         _p(self.grads[wname + ".bias"]), _p(ws), nbytes, n, cin, cout, hh, ww, 0)
             if side is None:
                 self._call(*args_)
-                return
-            ev = self._wgrad_events[n_wgrad[0]]
-            n_wgrad[0] += 1
-            ev.record(main)  # dy (and everything before it) is ready
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                self._call(*args_)
+            else:
+                ev = self._wgrad_events[n_wgrad[0]]
+                n_wgrad[0] += 1
+                ev.record(main)  # dy (and everything before it) is ready
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._call(*args_)
+            if WGRAD_BATCH_REDUCE:
+                jobs.append(_lib.WgradJob(_p(ws), _p(self.grads[wname + ".weight"]), _p(self.grads[wname + ".bias"]),
+                                          n_slabs.value, cin, cout, 0))
 
         for si in reversed(range(len(sp.stacks))):
             cin, cout, hh, ww, ho, wo = sp.stacks[si]
@@ -564,6 +578,13 @@ class DualHeadNet:
                 g = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
                 self._call("ppo_conv3x3_backward_data_f32", _p(dc), _p(self.params[f"encoder.stacks.{si}.firstconv.weight"]),
                            None, None, _p(g), B, cin, cout, hh, ww)
+        if jobs:
+            table = (_lib.WgradJob * len(jobs))(*jobs)
+            if side is None:
+                self._call("ppo_conv3x3_wgrad_reduce_f32", ctypes.addressof(table), len(jobs))
+            else:
+                with torch.cuda.stream(side):
+                    self._call("ppo_conv3x3_wgrad_reduce_f32", ctypes.addressof(table), len(jobs))
         if side is not None:
             main.wait_stream(side)  # all weight gradients are in self.grad before anything reads it
 

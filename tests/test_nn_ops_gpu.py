@@ -70,6 +70,39 @@ def test_conv_weight_grad(cin, cout, hw, mode, n):
     assert _close(dw, 2 * rw) and _close(db, 2 * rb)
 
 
+def test_conv_weight_grad_slabs_then_batched_reduce_is_bitwise_the_one_step_result():
+    """ppo_conv3x3_backward_weight_slabs_f32 + ppo_conv3x3_wgrad_reduce_f32 (the reductions of several layers in
+    one launch, incl. accumulate) against ppo_conv3x3_backward_weight_f32 on the same inputs: identical bits."""
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    layers = [(16, 16, 42, 1, 37), (32, 32, 11, 1, 64), (4, 16, 84, 0, 9), (16, 32, 42, 0, 20)]
+    jobs, keep, want = [], [], []
+    for cin, cout, hw, mode, n in layers:
+        x = torch.randn(n, cin, hw, hw, generator=g).to(DEV)
+        dy = torch.randn(n, cout, hw, hw, generator=g).to(DEV)
+        ws_bytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
+        ws1, ws2 = torch.empty(ws_bytes // 4, device=DEV), torch.empty(ws_bytes // 4, device=DEV)
+        dw1, db1 = torch.full((cout, cin, 3, 3), 0.5, device=DEV), torch.full((cout,), -2.0, device=DEV)
+        dw2, db2 = dw1.clone(), db1.clone()
+        acc = 1 if cin == 32 else 0  # one layer accumulates into existing gradients
+        _lib.check(lib.ppo_conv3x3_backward_weight_f32(_p(x), mode, _p(dy), _p(dw1), _p(db1), _p(ws1), ws_bytes, n, cin,
+                                                       cout, hw, hw, acc, _st()), "one step")
+        n_slabs = ctypes.c_int(0)
+        _lib.check(lib.ppo_conv3x3_backward_weight_slabs_f32(_p(x), mode, _p(dy), _p(ws2), ws_bytes, n, cin, cout, hw, hw,
+                                                             ctypes.addressof(n_slabs), _st()), "slabs")
+        assert n_slabs.value > 0
+        jobs.append(_lib.WgradJob(_p(ws2), _p(dw2), _p(db2), n_slabs.value, cin, cout, acc))
+        keep.append((x, dy, ws2))
+        want.append((dw1, db1, dw2, db2))
+    table = (_lib.WgradJob * len(jobs))(*jobs)
+    _lib.check(lib.ppo_conv3x3_wgrad_reduce_f32(ctypes.addressof(table), len(jobs), _st()), "reduce")
+    torch.cuda.synchronize()
+    for dw1, db1, dw2, db2 in want:
+        assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    assert lib.ppo_conv3x3_wgrad_reduce_f32(ctypes.addressof(table), 33, _st()) == -1  # too many jobs
+
+
 def test_conv_weight_grad_exact_on_integers():
     lib = _lib.load()
     g = torch.Generator().manual_seed(3)
