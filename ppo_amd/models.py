@@ -311,13 +311,22 @@ class DualHeadNet:
         self._call("ppo_gemm_f32", _p(x), k, 1, relu_x, _p(w), 1, k, 0, _p(self.params[wname + ".bias"]), None,
                    _p(out), n, B, n, k, _p(ws), ws_bytes)
 
-    def _linear_backward(self, x, k, wname, dy, dx, relu_x=0, mask=None, acc=0):
-        """dW = dy^T @ f(x), db = colsum(dy), dx = (dy @ W) [* (mask > 0)]  (dx nullable)."""
+    def _linear_backward(self, x, k, wname, dy, dx, relu_x=0, mask=None, acc=0, side=None):
+        """dW = dy^T @ f(x), db = colsum(dy), dx = (dy @ W) [* (mask > 0)]  (dx nullable).  With `side` (a stream
+        that already waits for dy) the two parameter gradients go there and only dx stays on the current stream."""
         w = self.params[wname + ".weight"]
         B, n = dy.shape[0], w.shape[0]
-        self._call("ppo_gemm_f32", _p(dy), 1, n, 0, _p(x), k, 1, relu_x, None, None, _p(self.grads[wname + ".weight"]), k,
-                   n, k, B, None, 0)
-        self._call("ppo_colsum_f32", _p(dy), B, n, n, _p(self.grads[wname + ".bias"]), acc)
+
+        def param_grads():
+            self._call("ppo_gemm_f32", _p(dy), 1, n, 0, _p(x), k, 1, relu_x, None, None,
+                       _p(self.grads[wname + ".weight"]), k, n, k, B, None, 0)
+            self._call("ppo_colsum_f32", _p(dy), B, n, n, _p(self.grads[wname + ".bias"]), acc)
+
+        if side is None:
+            param_grads()
+        else:
+            with torch.cuda.stream(side):
+                param_grads()
         if dx is not None:
             self._call("ppo_gemm_f32", _p(dy), n, 1, 0, _p(w), k, 1, 0, None, _p(mask), _p(dx), k, B, k, n, None, 0)
 
@@ -486,11 +495,24 @@ class DualHeadNet:
         h = acts["h"]
         relu = self.encoder_activation_fn == "relu"
         hin = h if relu else acts["hact"]
-        # heads: dW = dheads^T @ act(h); db = colsum(dheads); dh = (dheads @ W) * act'(h)
-        self._call("ppo_gemm_f32", _p(dheads), 1, self.nh, 0, _p(hin), H, 1, 1 if relu else 0, None, None,
-                   _p(self.g_w_heads), H, self.nh, H, B, None, 0)
-        if self.head_bias:
-            self._call("ppo_colsum_f32", _p(dheads), B, self.nh, self.nh, _p(self.g_b_heads), 0)
+        # heads: dW = dheads^T @ act(h); db = colsum(dheads); dh = (dheads @ W) * act'(h).  The parameter gradients
+        # (small, latency-bound launches) go to the side stream of the convolution weight gradients; the main stream
+        # carries only the dX chain.
+        main = torch.cuda.current_stream()
+        side = self._wgrad_side_stream() if (WGRAD_SIDE_STREAM and self.encoder_kind == "impala") else None
+
+        def head_param_grads():
+            self._call("ppo_gemm_f32", _p(dheads), 1, self.nh, 0, _p(hin), H, 1, 1 if relu else 0, None, None,
+                       _p(self.g_w_heads), H, self.nh, H, B, None, 0)
+            if self.head_bias:
+                self._call("ppo_colsum_f32", _p(dheads), B, self.nh, self.nh, _p(self.g_b_heads), 0)
+
+        if side is None:
+            head_param_grads()
+        else:
+            side.wait_stream(main)  # dheads (and the forward activations) are complete
+            with torch.cuda.stream(side):
+                head_param_grads()
         dh = self._buf("dh", (B, H))
         self._call("ppo_gemm_f32", _p(dheads), self.nh, 1, 0, _p(self.w_heads), H, 1, 0, None, _p(h) if relu else None,
                    _p(dh), H, B, H, self.nh, None, 0)
@@ -521,10 +543,12 @@ class DualHeadNet:
         # dense: dW = dh^T @ relu(flat); db = colsum(dh); dflat = (dh @ W) * (flat > 0)
         c_last, h_last, w_last = sp.out_shape
         g = self._buf(f"g{len(sp.stacks) - 1}_top", (B, c_last, h_last, w_last))
-        self._linear_backward(flat, sp.flat, "encoder.dense", dh, g, relu_x=1, mask=flat)
-
         main = torch.cuda.current_stream()
         side = self._wgrad_side_stream() if WGRAD_SIDE_STREAM else None
+        if side is not None:
+            side.wait_stream(main)  # dh is complete
+        self._linear_backward(flat, sp.flat, "encoder.dense", dh, g, relu_x=1, mask=flat, side=side)
+
         n_wgrad = [0]
 
         jobs = []  # deferred slab reductions: one launch for all layers at the end of the pass
