@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_* dense peak (MI355X_MICROARCH.md, Matrix cores)
+PROBE_TRAFFIC_BYTES = int((2 * 11295 + 15009) * 1024)  # conv3x3_kernel<32,32,21,21,IN_RELU> forward, batch 256
 SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write adv4+ret4
 FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
 
@@ -289,7 +290,14 @@ def main():
                                f"p_done 0.01)", "envs_per_gpu": A, "n_steps": N, "global_minibatch": mb * world,
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                     # HBM bytes per launch of this kernel at this shape: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+                     # separate passes over tools/conv_tune (counter collection around the whole PPO iteration
+                     # segfaults in rocprofv3 on this pool), 2 x FETCH_SIZE + WRITE_SIZE KiB as the guide prescribes
+                     # for gfx950; algorithmic = input + output = 28.9 MB, the 8/6 halo-row re-read accounts for the rest
+                     "traffic": PROBE_TRAFFIC_BYTES if mb == 256 else None,
+                     "traffic_source": "profiles/r01j_conv_hbm_traffic.md",
+                     "algorithmic_bytes_per_launch": 2 * 32 * 21 * 21 * 4 * mb,
                      "kernel": "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)",
                      "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
                      "launches_timed": len(probe.events)},
