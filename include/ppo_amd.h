@@ -126,6 +126,32 @@ int ppo_conv3x3_pool_forward_f32(const void *in, int in_mode, const float *weigh
                                  uint8_t *argmax, int n, int cin, int cout, int h, int w, void *stream);
 
 /*
+ * Pre-packed weights.  Each convolution kernel keeps its MFMA A operand in registers; from the raw [cout,cin,3,3]
+ * tensor a workgroup has to stage it through LDS first (two barriers and a global-load latency before the first
+ * MFMA of every launch).  ppo_conv3x3_pack_weights_f32 writes, for up to 32 layers in one launch, that operand in
+ * per-lane order — `transposed` = 0 for the forward kernels, 1 for backward-data (flipped, in/out swapped) —
+ * into buffers of ppo_conv3x3_packed_floats(cin, cout, transposed) floats (16-byte aligned); the *_packed_f32
+ * entry points are the convolutions above with `packed` in place of `weight` (cin / cout are always those of
+ * the FORWARD convolution).  Results are bit-identical; repack after every optimiser step.
+ */
+typedef struct ppo_pack_job {
+    const float *weight; /* raw [cout, cin, 3, 3] */
+    float *packed;       /* ppo_conv3x3_packed_floats(cin, cout, transposed) floats */
+    int cin, cout, transposed;
+} ppo_pack_job;
+size_t ppo_conv3x3_packed_floats(int cin, int cout, int transposed);
+int ppo_conv3x3_pack_weights_f32(const ppo_pack_job *jobs /* host */, int n_jobs, void *stream);
+int ppo_conv3x3_forward_packed_f32(const void *in, int in_mode, const float *packed, const float *bias,
+                                   const float *residual, float *out, int n, int cin, int cout, int h, int w,
+                                   void *stream);
+int ppo_conv3x3_backward_data_packed_f32(const float *dy, const float *packed, const float *relu_src,
+                                         const float *dres, float *dx, int n, int cin, int cout, int h, int w,
+                                         void *stream);
+int ppo_conv3x3_pool_forward_packed_f32(const void *in, int in_mode, const float *packed, const float *bias,
+                                        float *out, uint8_t *argmax, int n, int cin, int cout, int h, int w,
+                                        void *stream);
+
+/*
  * Weight and bias gradient of the same convolution (torch autograd of nn.Conv2d):
  *   dweight[o,i,ky,kx] (+)= sum_{n,y,x} dy[n,o,y,x] * f(in[n,i,y+ky-1,x+kx-1])    dbias[o] (+)= sum dy[n,o,y,x]
  * `in`/in_mode: the forward convolution's input and load transform.  workspace: scratch of at

@@ -57,6 +57,11 @@ SIGNATURES = {
     "ppo_synth_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ppo_conv3x3_pool_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_packed_floats": (_sz, [_i, _i, _i]),
+    "ppo_conv3x3_pack_weights_f32": (_i, [_vp, _i, _vp]),
+    "ppo_conv3x3_forward_packed_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_backward_data_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_pool_forward_packed_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_backward_weight_slabs_f32": (_i, [_vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_wgrad_reduce_f32": (_i, [_vp, _i, _vp]),
     "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),
@@ -68,6 +73,12 @@ SIGNATURES = {
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
 }
+
+class PackJob(ctypes.Structure):
+    """ppo_pack_job (include/ppo_amd.h)."""
+    _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+                ("transposed", ctypes.c_int)]
+
 
 class WgradJob(ctypes.Structure):
     """ppo_wgrad_job (include/ppo_amd.h)."""

@@ -57,6 +57,46 @@ __device__ unsigned long long ppo_tune_stamps[8 * 8 * 1024];  // [workgroup][wav
 #define PPO_STAMP_ADD(slot, t1, t0)
 #endif
 
+// Set by the *_packed_f32 entry points around their dispatch: `weight` is then the pre-packed A operand
+// (ppo_conv3x3_pack_weights_f32) instead of the raw [O][I][3][3] tensor.  Host-side, thread-local, consumed by the
+// launch a few frames down the same call.
+thread_local int t_weights_packed = 0;
+
+// Packed A operand of a kernel with (kernel-side) CIN input and COUT output channels: for K step s = tap*CINP/4 + cs
+// and channel tile n, lane (l15, g) holds w(co = n*16 + l15, ci = cs*4 + g, tap); four consecutive steps form one
+// float4 so a wave's load is 1 KB contiguous:  packed[((s/4 * NT + n) * 64 + lane) * 4 + s % 4].
+__host__ __device__ constexpr int packed_floats(int cin, int cout)
+{
+    const int ks = 9 * (((cin + 3) / 4 * 4) / 4), nt = ((cout + 15) / 16 * 16) / 16;
+    return (ks + 3) / 4 * 4 * nt * 64;
+}
+
+struct PackJobs {
+    ppo_pack_job j[32];
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackJobs jobs)
+{
+    const ppo_pack_job &job = jobs.j[blockIdx.y];
+    // kernel-side channel counts: the transposed (backward-data) kernel contracts over the forward's outputs
+    const int cin = job.transposed ? job.cout : job.cin, cout = job.transposed ? job.cin : job.cout;
+    const int cinp = (cin + 3) / 4 * 4, nt = ((cout + 15) / 16 * 16) / 16;
+    const int ks = 9 * (cinp / 4);
+    const int total = (ks + 3) / 4 * 4 * nt * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i & 3, lane = (i >> 2) & 63, rest = i >> 8;  // rest = s4 * nt + n
+        const int n = rest % nt, s = (rest / nt) * 4 + e;
+        float v = 0.f;
+        if (s < ks) {
+            const int tap = s / (cinp / 4), ci = (s % (cinp / 4)) * 4 + (lane >> 4), co = n * 16 + (lane & 15);
+            if (ci < cin && co < cout)
+                v = job.transposed ? job.weight[((size_t)ci * cout + co) * 9 + (8 - tap)]  // raw [O = ci][I = co], flipped
+                                   : job.weight[((size_t)co * cin + ci) * 9 + tap];
+        }
+        job.packed[i] = v;
+    }
+}
+
 template <int CIN, int COUT, int H, int W, int TR, bool DOUBLE>
 struct ConvCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;  // k-steps of 4 channels
@@ -75,7 +115,7 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(NBUF * LDS_IN) * 4;
 };
 
-template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED>
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     const void *__restrict__ in_, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ residual, const float *__restrict__ mask_src, float *__restrict__ out,
@@ -106,26 +146,43 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     // The transposed (backward-data) gather already touches few cache lines per request (lanes step through
     // the contiguous [I][3][3] part of the tensor) and measured slightly faster straight from global memory.
     constexpr bool VIA_LDS = !TRANSPOSED;
-    if constexpr (VIA_LDS) {
-        for (int i = tid; i < WR * WL; i += kConvThreads) smem[(i / WL) * WLP + i % WL] = w[i];
-        __syncthreads();
-    }
     float wa[C::NT][KS];
+    if constexpr (PACKED) {
+        // `w` is this kernel's A operand already in per-lane order (ppo_conv3x3_pack_weights_f32): 16-byte coalesced
+        // loads, no LDS round trip, no barrier — they are in flight while the band buffers are zeroed and the
+        // first band is requested, and are first needed in the K loop.
+        const float4 *pw = reinterpret_cast<const float4 *>(w);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int tap = s / (C::CINP / 4);
-        const int ci = (s % (C::CINP / 4)) * 4 + g;  // this lane group contracts k = 4s + g
+        for (int s4 = 0; s4 < (KS + 3) / 4; ++s4)
 #pragma unroll
-        for (int n = 0; n < C::NT; ++n) {
-            const int co = n * 16 + l15;
-            float v = 0.f;
-            if (ci < CIN && co < COUT)
-                v = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
-                               : smem[co * WLP + ci * 9 + tap];
-            wa[n][s] = v;
+            for (int n = 0; n < C::NT; ++n) {
+                const float4 v = pw[(s4 * C::NT + n) * 64 + lane];
+                if (4 * s4 + 0 < KS) wa[n][4 * s4 + 0] = v.x;
+                if (4 * s4 + 1 < KS) wa[n][4 * s4 + 1] = v.y;
+                if (4 * s4 + 2 < KS) wa[n][4 * s4 + 2] = v.z;
+                if (4 * s4 + 3 < KS) wa[n][4 * s4 + 3] = v.w;
+            }
+    } else {
+        if constexpr (VIA_LDS) {
+            for (int i = tid; i < WR * WL; i += kConvThreads) smem[(i / WL) * WLP + i % WL] = w[i];
+            __syncthreads();
         }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int tap = s / (C::CINP / 4);
+            const int ci = (s % (C::CINP / 4)) * 4 + g;  // this lane group contracts k = 4s + g
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n) {
+                const int co = n * 16 + l15;
+                float v = 0.f;
+                if (ci < CIN && co < COUT)
+                    v = TRANSPOSED ? w[((size_t)ci * COUT + co) * 9 + (8 - tap)]  // w[o=ci][i=co], taps flipped
+                                   : smem[co * WLP + ci * 9 + tap];
+                wa[n][s] = v;
+            }
+        }
+        if constexpr (VIA_LDS) __syncthreads();  // every lane has its weights: the region is reused for the input bands
     }
-    if constexpr (VIA_LDS) __syncthreads();  // every lane has its weights: the region is reused for the input bands
     // this lane's bias values (channels n*16 + g*4 + r), loaded once
     float bias_r[C::NT][4];
 #pragma unroll
@@ -387,12 +444,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     flush();
 }
 
-template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED>
-int launch_conv(const void *in, const float *w, const float *bias, const float *residual,
-                const float *mask_src, float *out, int n_images, hipStream_t st)
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED, bool PACKED>
+int launch_conv_impl(const void *in, const float *w, const float *bias, const float *residual,
+                     const float *mask_src, float *out, int n_images, hipStream_t st)
 {
     using C = ConvCfg<CIN, COUT, H, W, TR, IN_MODE != IN_U8>;
-    auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED>;
+    auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, PACKED>;
     constexpr int kConvThreads = NW * 64;
     // the band buffers, or the padded weight image the prologue stages through the same region
     constexpr size_t kWeightImage = (size_t)(TRANSPOSED ? CIN : COUT) * (((TRANSPOSED ? COUT : CIN) * 9) | 1) * 4;
@@ -416,6 +473,19 @@ int launch_conv(const void *in, const float *w, const float *bias, const float *
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kConvThreads), kLdsBytes, st, in, w, bias, residual, mask_src, out,
                        n_images);
     return check_launch("conv3x3_kernel");
+}
+
+// raw-weight and packed-weight forms are separate instantiations (a runtime branch between the two prologues cost
+// the backward-data kernels 8 %: 1.56 -> 1.70 ms per minibatch)
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED>
+int launch_conv(const void *in, const float *w, const float *bias, const float *residual, const float *mask_src,
+                float *out, int n_images, hipStream_t st)
+{
+    if (t_weights_packed)
+        return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, true>(in, w, bias, residual, mask_src,
+                                                                                         out, n_images, st);
+    return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, false>(in, w, bias, residual, mask_src, out,
+                                                                                      n_images, st);
 }
 
 // Supported layer geometries: Atari 84x84 (rl/atari.py) and Procgen 64x64 (rl/procgen.py)
@@ -487,7 +557,7 @@ struct ConvPoolCfg {
     static constexpr size_t LDS_BYTES = (size_t)(NBUF * LDS_IN + LDS_OUT) * 4;
 };
 
-template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE>
+template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__restrict__ in_, const float *__restrict__ w,
                                                               const float *__restrict__ bias, float *__restrict__ out,
                                                               uint8_t *__restrict__ argmax, int n_images)
@@ -507,20 +577,34 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     // weights -> registers through LDS (see conv3x3_kernel)
     constexpr int KS = 9 * (C::CINP / 4);
     constexpr int WL = CIN * 9, WLP = WL | 1;
-    for (int i = tid; i < COUT * WL; i += kThreads) smem[(i / WL) * WLP + i % WL] = w[i];
-    __syncthreads();
     float wa[C::NT][KS];
+    if constexpr (PACKED) {  // pre-packed A operand (see conv3x3_kernel)
+        const float4 *pw = reinterpret_cast<const float4 *>(w);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int tap = s / (C::CINP / 4);
-        const int ci = (s % (C::CINP / 4)) * 4 + g;
+        for (int s4 = 0; s4 < (KS + 3) / 4; ++s4)
 #pragma unroll
-        for (int n = 0; n < C::NT; ++n) {
-            const int co = n * 16 + l15;
-            wa[n][s] = (ci < CIN && co < COUT) ? smem[co * WLP + ci * 9 + tap] : 0.f;
+            for (int n = 0; n < C::NT; ++n) {
+                const float4 v = pw[(s4 * C::NT + n) * 64 + lane];
+                if (4 * s4 + 0 < KS) wa[n][4 * s4 + 0] = v.x;
+                if (4 * s4 + 1 < KS) wa[n][4 * s4 + 1] = v.y;
+                if (4 * s4 + 2 < KS) wa[n][4 * s4 + 2] = v.z;
+                if (4 * s4 + 3 < KS) wa[n][4 * s4 + 3] = v.w;
+            }
+    } else {
+        for (int i = tid; i < COUT * WL; i += kThreads) smem[(i / WL) * WLP + i % WL] = w[i];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int tap = s / (C::CINP / 4);
+            const int ci = (s % (C::CINP / 4)) * 4 + g;
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n) {
+                const int co = n * 16 + l15;
+                wa[n][s] = (ci < CIN && co < COUT) ? smem[co * WLP + ci * 9 + tap] : 0.f;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float bias_r[C::NT][4];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n)
@@ -669,12 +753,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     }
 }
 
-template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE>
-int launch_conv_pool(const void *in, const float *w, const float *bias, float *out, uint8_t *argmax, int n_images,
-                     hipStream_t st)
+template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE, bool PACKED>
+int launch_conv_pool_impl(const void *in, const float *w, const float *bias, float *out, uint8_t *argmax, int n_images,
+                          hipStream_t st)
 {
     using C = ConvPoolCfg<CIN, COUT, H, W, PR, IN_MODE != IN_U8>;
-    auto kern = conv3x3_pool_kernel<CIN, COUT, H, W, PR, MT, NW, IN_MODE>;
+    auto kern = conv3x3_pool_kernel<CIN, COUT, H, W, PR, MT, NW, IN_MODE, PACKED>;
     constexpr size_t kWeightImage = (size_t)COUT * ((CIN * 9) | 1) * 4;
     constexpr size_t kLdsBytes = C::LDS_BYTES > kWeightImage ? C::LDS_BYTES : kWeightImage;
     static_assert(kLdsBytes <= 160 * 1024, "band + pre-pool rows must fit the 160 KB of LDS");
@@ -693,6 +777,15 @@ int launch_conv_pool(const void *in, const float *w, const float *bias, float *o
     if (grid > n_items) grid = n_items;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), kLdsBytes, st, in, w, bias, out, argmax, n_images);
     return check_launch("conv3x3_pool_kernel");
+}
+
+template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE>
+int launch_conv_pool(const void *in, const float *w, const float *bias, float *out, uint8_t *argmax, int n_images,
+                     hipStream_t st)
+{
+    if (t_weights_packed)
+        return launch_conv_pool_impl<CIN, COUT, H, W, PR, MT, NW, IN_MODE, true>(in, w, bias, out, argmax, n_images, st);
+    return launch_conv_pool_impl<CIN, COUT, H, W, PR, MT, NW, IN_MODE, false>(in, w, bias, out, argmax, n_images, st);
 }
 
 template <int IN_MODE>
@@ -778,4 +871,55 @@ extern "C" int ppo_conv3x3_pool_forward_f32(const void *in, int in_mode, const f
         case IN_U8: return dispatch_conv_pool<IN_U8>(cin, cout, h, w, in, weight, bias, out, argmax, n, st);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_pool_forward_f32: in_mode %d (the stack-first convolution reads raw input)", in_mode);
+}
+
+extern "C" size_t ppo_conv3x3_packed_floats(int cin, int cout, int transposed)
+{
+    return (size_t)(transposed ? ppo::packed_floats(cout, cin) : ppo::packed_floats(cin, cout));
+}
+
+extern "C" int ppo_conv3x3_pack_weights_f32(const ppo_pack_job *jobs, int n_jobs, void *stream)
+{
+    using namespace ppo;
+    if (n_jobs < 0 || n_jobs > 32) return fail(PPO_E_INVALID, "ppo_conv3x3_pack_weights_f32: 0..32 jobs per call");
+    if (n_jobs == 0) return PPO_OK;
+    if (!jobs) return fail(PPO_E_INVALID, "ppo_conv3x3_pack_weights_f32: null jobs");
+    PackJobs pj;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].weight || !jobs[i].packed || jobs[i].cin <= 0 || jobs[i].cout <= 0 || !aligned(jobs[i].packed, 16))
+            return fail(PPO_E_INVALID, "ppo_conv3x3_pack_weights_f32: bad job %d", i);
+        pj.j[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(40, n_jobs), dim3(256), 0, as_stream(stream), pj);
+    return check_launch("pack_weights_kernel");
+}
+
+extern "C" int ppo_conv3x3_forward_packed_f32(const void *in, int in_mode, const float *packed, const float *bias,
+                                              const float *residual, float *out, int n, int cin, int cout, int h,
+                                              int w, void *stream)
+{
+    ppo::t_weights_packed = 1;
+    const int rc = ppo_conv3x3_forward_f32(in, in_mode, packed, bias, residual, out, n, cin, cout, h, w, stream);
+    ppo::t_weights_packed = 0;
+    return rc;
+}
+
+extern "C" int ppo_conv3x3_backward_data_packed_f32(const float *dy, const float *packed, const float *relu_src,
+                                                    const float *dres, float *dx, int n, int cin, int cout, int h,
+                                                    int w, void *stream)
+{
+    ppo::t_weights_packed = 1;
+    const int rc = ppo_conv3x3_backward_data_f32(dy, packed, relu_src, dres, dx, n, cin, cout, h, w, stream);
+    ppo::t_weights_packed = 0;
+    return rc;
+}
+
+extern "C" int ppo_conv3x3_pool_forward_packed_f32(const void *in, int in_mode, const float *packed, const float *bias,
+                                                   float *out, uint8_t *argmax, int n, int cin, int cout, int h,
+                                                   int w, void *stream)
+{
+    ppo::t_weights_packed = 1;
+    const int rc = ppo_conv3x3_pool_forward_f32(in, in_mode, packed, bias, out, argmax, n, cin, cout, h, w, stream);
+    ppo::t_weights_packed = 0;
+    return rc;
 }

@@ -31,6 +31,9 @@ FUSE_POOL_STACKS = int(os.environ.get("PPO_AMD_FUSE_POOL", "7"))
 WGRAD_SIDE_STREAM = int(os.environ.get("PPO_AMD_WGRAD_STREAM", "1"))
 # the slab reductions of all convolution layers in one launch at the end of the backward pass (0 = one per layer)
 WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
+# convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
+# optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
+PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -213,6 +216,7 @@ class DualHeadNet:
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._rec = None   # launch recorder (see encode)
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
+        self._build_packed_weights()
         self._adam_step = 0
         self.exp_avg = None
         self.exp_avg_sq = None
@@ -271,7 +275,48 @@ class DualHeadNet:
         names = ["log_std"] + [n for n in self._state_order if n != "log_std"]
         return OrderedDict((n, self.params[n]) for n in names)
 
+    # ------------------------------------------------------------------ pre-packed convolution weights
+    def _build_packed_weights(self):
+        """One buffer with, per convolution, the forward kernels' A operand and the backward-data kernels' (flipped,
+        transposed) one in per-lane order, plus the job table of the launch that refreshes all of them."""
+        self._pk, self._pack_table, self._packed_dirty = {}, None, False
+        if not PACKED_WEIGHTS or self.encoder_kind != "impala":
+            return
+        jobs, total = [], 0
+        for name, w in self.params.items():
+            if not (name.startswith("encoder.stacks.") and name.endswith(".weight")):
+                continue
+            cout, cin = int(w.shape[0]), int(w.shape[1])
+            for transposed in (0, 1):
+                if transposed and name == "encoder.stacks.0.firstconv.weight":
+                    continue  # nothing back-propagates into the observations
+                n = int(self.lib.ppo_conv3x3_packed_floats(cin, cout, transposed))
+                jobs.append((name[:-len(".weight")], transposed, cin, cout, total, n))
+                total += n
+        self._packed = torch.zeros(total, dtype=torch.float32, device=self.device)
+        table = (_lib.PackJob * len(jobs))()
+        for k, (wname, transposed, cin, cout, off, n) in enumerate(jobs):
+            view = self._packed[off:off + n]
+            self._pk[(wname, transposed)] = view
+            table[k] = _lib.PackJob(_p(self.params[wname + ".weight"]), _p(view), cin, cout, transposed)
+        self._pack_table = table
+        self._packed_dirty = True
+
+    def mark_weights_changed(self):
+        """Call after writing convolution weights other than through adam_step / load_state_dict."""
+        self._packed_dirty = self._pack_table is not None
+
+    def _refresh_packed(self):
+        if self._packed_dirty:
+            self._packed_dirty = False
+            rec, self._rec = self._rec, None  # never part of a recorded forward: the refresh is conditional
+            try:
+                self._call("ppo_conv3x3_pack_weights_f32", ctypes.addressof(self._pack_table), len(self._pack_table))
+            finally:
+                self._rec = rec
+
     def load_state_dict(self, sd, strict=True):
+        self.mark_weights_changed()
         missing = [n for n in self.params if n not in sd]
         unexpected = [n for n in sd if n not in self.params]
         if strict and (missing or unexpected):
@@ -332,6 +377,11 @@ class DualHeadNet:
 
     # ------------------------------------------------------------------ forward
     def _conv(self, x, mode, wname, out, residual, n, cin, cout, h, w):
+        pk = self._pk.get((wname, 0))
+        if pk is not None:
+            self._call("ppo_conv3x3_forward_packed_f32", _p(x), mode, _p(pk), _p(self.params[wname + ".bias"]),
+                       _p(residual), _p(out), n, cin, cout, h, w)
+            return
         self._call("ppo_conv3x3_forward_f32", _p(x), mode, _p(self.params[wname + ".weight"]),
                    _p(self.params[wname + ".bias"]), _p(residual), _p(out), n, cin, cout, h, w)
 
@@ -342,6 +392,7 @@ class DualHeadNet:
         forwards that overlap on different streams use different tags."""
         sp = self.spec
         tag = tag or ("t" if train else "i")
+        self._refresh_packed()
         if tuple(x.shape[1:]) != sp.input_dims:
             raise ValueError(f"expected input [B, {sp.input_dims}], got {tuple(x.shape)}")
         if x.dtype not in (torch.uint8, torch.float32) or not x.is_contiguous() or x.device != self.device:
@@ -403,7 +454,9 @@ class DualHeadNet:
             wname = f"encoder.stacks.{si}.firstconv"
             if FUSE_POOL_STACKS >> si & 1:
                 # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
-                self._call("ppo_conv3x3_pool_forward_f32", _p(cur), cur_mode, _p(self.params[wname + ".weight"]),
+                pk = self._pk.get((wname, 0))
+                self._call("ppo_conv3x3_pool_forward_f32" if pk is None else "ppo_conv3x3_pool_forward_packed_f32",
+                           _p(cur), cur_mode, _p(self.params[wname + ".weight"] if pk is None else pk),
                            _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
             else:
                 c = self._buf(f"{tag}c{si}", (B, cout, h, w))
@@ -585,11 +638,11 @@ class DualHeadNet:
                 # g = d loss / d (block output);  block: out = q_in + conv1(relu(conv0(relu(q_in))))
                 wgrad(a, IN_RELU, g, base + ".conv1", B, cout, cout, ho, wo)
                 da = self._buf(f"g{si}_{bi}_da", (B, cout, ho, wo))
-                self._call("ppo_conv3x3_backward_data_f32", _p(g), _p(self.params[base + ".conv1.weight"]), _p(a), None,
+                self._call(self._bwd_data_fn(base + ".conv1"), _p(g), _p(self._bwd_w(base + ".conv1")), _p(a), None,
                            _p(da), B, cout, cout, ho, wo)
                 wgrad(q_in, IN_RELU, da, base + ".conv0", B, cout, cout, ho, wo)
                 gn = self._buf(f"g{si}_{bi}_in", (B, cout, ho, wo))
-                self._call("ppo_conv3x3_backward_data_f32", _p(da), _p(self.params[base + ".conv0.weight"]), _p(q_in),
+                self._call(self._bwd_data_fn(base + ".conv0"), _p(da), _p(self._bwd_w(base + ".conv0")), _p(q_in),
                            _p(g), _p(gn), B, cout, cout, ho, wo)
                 g = gn
             # max-pool backward, then the stack's first convolution
@@ -600,7 +653,8 @@ class DualHeadNet:
             wgrad(x_in, mode, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
             if si > 0:
                 g = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
-                self._call("ppo_conv3x3_backward_data_f32", _p(dc), _p(self.params[f"encoder.stacks.{si}.firstconv.weight"]),
+                fc = f"encoder.stacks.{si}.firstconv"
+                self._call(self._bwd_data_fn(fc), _p(dc), _p(self._bwd_w(fc)),
                            None, None, _p(g), B, cin, cout, hh, ww)
         if jobs:
             table = (_lib.WgradJob * len(jobs))(*jobs)
@@ -611,6 +665,12 @@ class DualHeadNet:
                     self._call("ppo_conv3x3_wgrad_reduce_f32", ctypes.addressof(table), len(jobs))
         if side is not None:
             main.wait_stream(side)  # all weight gradients are in self.grad before anything reads it
+
+    def _bwd_data_fn(self, wname):
+        return "ppo_conv3x3_backward_data_packed_f32" if (wname, 1) in self._pk else "ppo_conv3x3_backward_data_f32"
+
+    def _bwd_w(self, wname):
+        return self._pk.get((wname, 1), self.params[wname + ".weight"])
 
     def _wgrad_side_stream(self):
         if getattr(self, "_wgrad_stream", None) is None:
@@ -693,6 +753,7 @@ class DualHeadNet:
         `state`: a separate set of Adam moments over the same parameters (the reference's distil optimiser,
         rl/rollout.py:136-141); default is the net's own."""
         ws = self._ws("adam_ws", self.lib.ppo_adam_workspace_bytes())
+        self.mark_weights_changed()
         if state is not None:
             state.ensure(self.flat)
             state.step += 1

@@ -146,3 +146,54 @@ def test_fused_conv_pool_equals_conv_then_pool_bitwise(cin, cout, hw, u8, n):
     _lib.check(lib.ppo_conv3x3_pool_forward_f32(_p(x), mode, _p(w), _p(b), _p(p2), None, n, cin, cout, hw, hw,
                                                 _lib.current_stream()), "ppo_conv3x3_pool_forward_f32")
     assert torch.equal(p2, p_ref)
+
+
+@pytest.mark.parametrize("cin,cout,hw", GEOMS)
+def test_packed_weights_give_the_raw_weight_results_bitwise(cin, cout, hw):
+    """ppo_conv3x3_pack_weights_f32 + the *_packed_f32 entry points (forward, backward-data, fused conv+pool)
+    against the raw-weight entry points on the same inputs: identical bits (only where the A operand comes from
+    changes, not the arithmetic)."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(cin * 31 + cout + hw)
+    n = 9
+    w = torch.randn(cout, cin, 3, 3, generator=g, device=dev)
+    b = torch.randn(cout, generator=g, device=dev)
+    pf = torch.full((lib.ppo_conv3x3_packed_floats(cin, cout, 0),), float("nan"), device=dev)
+    pb = torch.full((lib.ppo_conv3x3_packed_floats(cin, cout, 1),), float("nan"), device=dev)
+    jobs = (_lib.PackJob * 2)(_lib.PackJob(_p(w), _p(pf), cin, cout, 0), _lib.PackJob(_p(w), _p(pb), cin, cout, 1))
+    _lib.check(lib.ppo_conv3x3_pack_weights_f32(ctypes.addressof(jobs), 2, _lib.current_stream()), "pack")
+    torch.cuda.synchronize()
+    assert torch.isfinite(pf).all() and torch.isfinite(pb).all()
+    assert abs(float(pf.abs().sum()) - float(w.abs().sum())) < 1e-2 * float(w.abs().sum())  # a permutation + zero padding
+    # forward (ReLU-on-load + residual where the geometry allows it: cin == cout)
+    relu_ok = cin == cout
+    x = torch.randn(n, cin, hw, hw, generator=g, device=dev)
+    res = torch.randn(n, cout, hw, hw, generator=g, device=dev) if relu_ok else None
+    mode = 1 if relu_ok else 0
+    want = conv_fwd(x, w, b, res, mode)
+    got = torch.empty_like(want)
+    _lib.check(lib.ppo_conv3x3_forward_packed_f32(_p(x), mode, _p(pf), _p(b), _p(res), _p(got), n, cin, cout, hw, hw,
+                                                  _lib.current_stream()), "fwd packed")
+    assert torch.equal(got, want)
+    # backward-data (exists for every layer that is not the observation conv)
+    if cin >= 16:
+        dy = torch.randn(n, cout, hw, hw, generator=g, device=dev)
+        dx1, dx2 = torch.empty(n, cin, hw, hw, device=dev), torch.empty(n, cin, hw, hw, device=dev)
+        _lib.check(lib.ppo_conv3x3_backward_data_f32(_p(dy), _p(w), _p(x), None, _p(dx1), n, cin, cout, hw, hw,
+                                                     _lib.current_stream()), "bwd")
+        _lib.check(lib.ppo_conv3x3_backward_data_packed_f32(_p(dy), _p(pb), _p(x), None, _p(dx2), n, cin, cout, hw, hw,
+                                                            _lib.current_stream()), "bwd packed")
+        assert torch.equal(dx1, dx2)
+    # fused conv + pool (stack-first geometries)
+    if (cin, cout, hw) in [(4, 16, 84), (5, 16, 84), (3, 16, 64), (16, 32, 42), (16, 32, 32), (32, 32, 21), (32, 32, 16)]:
+        ho = (hw + 1) // 2
+        p1, p2 = torch.empty(n, cout, ho, ho, device=dev), torch.empty(n, cout, ho, ho, device=dev)
+        i1 = torch.empty(n, cout, ho, ho, device=dev, dtype=torch.uint8)
+        i2 = torch.empty_like(i1)
+        _lib.check(lib.ppo_conv3x3_pool_forward_f32(_p(x), 0, _p(w), _p(b), _p(p1), _p(i1), n, cin, cout, hw, hw,
+                                                    _lib.current_stream()), "pool")
+        _lib.check(lib.ppo_conv3x3_pool_forward_packed_f32(_p(x), 0, _p(pf), _p(b), _p(p2), _p(i2), n, cin, cout, hw, hw,
+                                                           _lib.current_stream()), "pool packed")
+        assert torch.equal(p1, p2) and torch.equal(i1, i2)
