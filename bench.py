@@ -97,7 +97,7 @@ class CallProbe:
         net._call = self._call
 
     def _call(self, fn_name, *a):
-        if self.enabled and fn_name == self.fn_name and self.match(a):
+        if self.enabled and fn_name in self.fn_name and self.match(a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._orig(fn_name, *a)
@@ -235,7 +235,7 @@ def main():
     runner.reset()
     # dominant kernel of the step (profiles/r01e: largest total time): the 32->32 21x21 forward convolution of the
     # residual blocks, conv3x3_kernel<32,32,21,21,..,IN_RELU>; the train-minibatch launches (n == mb) are timed
-    probe = CallProbe(model.policy_net, "ppo_conv3x3_forward_f32",
+    probe = CallProbe(model.policy_net, ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32"),
                       lambda c: c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (mb, 32, 32, 21, 21))
     probe_flops = 2 * 9 * 32 * 32 * 21 * 21 * mb
 
@@ -266,6 +266,8 @@ def main():
     stats = runner.fetch_stats()
 
     env_steps = world * N * A * a.steps
+    if not probe.events:
+        raise SystemExit("bench.py: the roofline probe saw no launch of its kernel (entry point renamed?)")
     kern_ms = probe.avg_ms()
     tflops = probe_flops / (kern_ms * 1e-3) / 1e12
     samples_fwd = (N + 1) * A + args.policy_opt.epochs * N * A
