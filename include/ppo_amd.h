@@ -354,6 +354,26 @@ int ppo_tvf_returns_f32(const float *rewards, const uint8_t *dones, const float 
                         size_t workspace_bytes, float *out, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Observation normalisation (`--observation_normalization`, rl/models.py:661-694): running per-feature
+ * mean / variance (utils.RunningMeanStd, rl/utils.py:379-455) kept on the device in float64, and the
+ * transform clamp((x - mu) / (std + eps), -5, 5) applied to the prepared observation (uint8 -> x/255,
+ * float32 as is; rl/models.py:824-856) before either network.  x is [B, F] (F = product of input_dims).
+ *
+ * ppo_obs_moments_f64:     moments[0:F] = sum_b x, moments[F:2F] = sum_b x^2 in float64 (additive across
+ *                          data-parallel ranks: all-reduce before the update).
+ * ppo_obs_rms_update_f64:  RunningMeanStd.update_from_moments with batch mean / var taken from `moments`
+ *                          over batch_count observations; `count` is the running count BEFORE this batch
+ *                          (the caller adds batch_count afterwards).  Also refreshes the float32 constants
+ *                          mu = mean, std = sqrt(float32(var))  (refresh_normalization_constants, :661-663).
+ * ppo_obs_normalize_f32:   out [B, F] float32; bit-identical to the torch expression at :692.
+ * ---------------------------------------------------------------------- */
+int ppo_obs_moments_f64(const void *x, int is_u8, int B, int F, double *moments, void *stream);
+int ppo_obs_rms_update_f64(const double *moments, double batch_count, double count, double *mean, double *var,
+                           float *mu, float *std, int F, void *stream);
+int ppo_obs_normalize_f32(const void *x, int is_u8, const float *mu, const float *std, float eps, float *out, int B,
+                          int F, void *stream);
+
+/* ------------------------------------------------------------------------
  * Synthetic vectorised environment (HOST pointers; runs on host threads).
  * The benchmark workload of SURVEY.md §8(d): obs uint8 i.i.d. uniform, reward ~ N(0,1),
  * done ~ Bernoulli(p_done), auto-reset; stands where the reference has the

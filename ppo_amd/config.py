@@ -162,6 +162,8 @@ class Config:
         self.device = "cpu"            # :731 (the reference default; this build requires a GPU)
         self.upload_batch = False      # :732
         self.observation_normalization = False  # :756
+        self.observation_normalization_epsilon = 0.003  # :757
+        self.freeze_observation_normalization = False  # :758
         self.observation_scaling = "scaled"     # :755
         self.seed = -1                 # :749
         self.epochs = 50.0             # millions of env steps
@@ -224,6 +226,8 @@ class Config:
         a("--device", type=str, default=self.device)
         a("--upload_batch", type=str2bool, nargs="?", const=True, default=self.upload_batch)
         a("--observation_normalization", type=str2bool, nargs="?", const=True, default=False)
+        a("--observation_normalization_epsilon", type=float, default=0.003)
+        a("--freeze_observation_normalization", type=str2bool, nargs="?", const=True, default=False)
         a("--observation_scaling", type=str, default="scaled")
         a("--seed", type=int, default=self.seed)
         a("--epochs", type=float, default=self.epochs, help="millions of env steps to train for")

@@ -168,6 +168,69 @@ class AdamState:
             self.exp_avg_sq = torch.zeros_like(flat)
 
 
+class ObsNormalizer:
+    """Device-resident form of the reference's observation normaliser (rl/models.py:615-617, 661-694):
+    `obs_rms` (utils.RunningMeanStd: float64 mean / var per feature, scalar count) plus the float32 constants
+    `_mu` / `_std`.  One instance is shared by the policy and value nets of a TVFModel; each net applies it in
+    `encode`.  Data-parallel ranks all-reduce the batch moments, so every rank holds the same statistics."""
+
+    def __init__(self, input_dims, device, norm_eps: float = 1e-5, frozen: bool = False, epsilon: float = 1e-4):
+        self.input_dims = tuple(int(d) for d in input_dims)
+        self.F = int(np.prod(self.input_dims))
+        self.device = torch.device(device)
+        self.norm_eps, self.frozen = float(norm_eps), bool(frozen)
+        self.mean = torch.zeros(self.F, dtype=torch.float64, device=self.device)
+        self.var = torch.ones(self.F, dtype=torch.float64, device=self.device)
+        self.count = float(epsilon)
+        self.mu = torch.zeros(self.F, dtype=torch.float32, device=self.device)
+        self.std = torch.ones(self.F, dtype=torch.float32, device=self.device)
+        self._moments = torch.empty(2 * self.F, dtype=torch.float64, device=self.device)
+        self.device = self.mean.device  # 'cuda' -> 'cuda:0', comparable with tensors' devices
+        self.lib = _lib.load()
+
+    def _call(self, fn_name, *args):
+        rc = getattr(self.lib, fn_name)(*args, _lib.current_stream())
+        if rc != 0:
+            _lib.check(rc, fn_name)
+
+    def _check(self, x):
+        if tuple(x.shape[1:]) != self.input_dims or x.dtype not in (torch.uint8, torch.float32) \
+                or not x.is_contiguous() or x.device != self.device:
+            raise ValueError(f"expected a contiguous uint8/float32 [B, {self.input_dims}] tensor on {self.device}")
+
+    def update(self, x: torch.Tensor):
+        """perform_normalization(..., update_normalization=True)'s statistics update (rl/models.py:681-687)."""
+        if self.frozen or x.shape[0] == 0:
+            return
+        self._check(x)
+        from . import parallel
+        self._call("ppo_obs_moments_f64", _p(x), 1 if x.dtype == torch.uint8 else 0, x.shape[0], self.F,
+                   _p(self._moments))
+        n = x.shape[0]
+        if parallel.world_size() > 1:
+            parallel.allreduce_sum_(self._moments)
+            n *= parallel.world_size()
+        self._call("ppo_obs_rms_update_f64", _p(self._moments), float(n), self.count, _p(self.mean), _p(self.var),
+                   _p(self.mu), _p(self.std), self.F)
+        self.count += n
+
+    def apply(self, x: torch.Tensor, out: torch.Tensor):
+        self._check(x)
+        self._call("ppo_obs_normalize_f32", _p(x), 1 if x.dtype == torch.uint8 else 0, _p(self.mu), _p(self.std),
+                   self.norm_eps, _p(out), x.shape[0], self.F)
+        return out
+
+    def state_dict(self):
+        return {"mean": self.mean.cpu(), "var": self.var.cpu(), "count": float(self.count)}
+
+    def load_state_dict(self, sd):
+        self.mean.copy_(torch.as_tensor(sd["mean"], dtype=torch.float64).reshape(self.F))
+        self.var.copy_(torch.as_tensor(sd["var"], dtype=torch.float64).reshape(self.F))
+        self.count = float(sd["count"])
+        self.mu.copy_(self.mean.float())                # refresh_normalization_constants, rl/models.py:661-663
+        self.std.copy_(self.var.float().sqrt())
+
+
 class DualHeadNet:
     """One encoder + policy / value / advantage (/ TVF) heads (reference: rl/models.py:304-508), HIP-backed.
 
@@ -215,6 +278,7 @@ class DualHeadNet:
         self._build_parameters(head_scale)
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._rec = None   # launch recorder (see encode)
+        self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self._build_packed_weights()
         self._adam_step = 0
@@ -411,13 +475,22 @@ class DualHeadNet:
                 if rc != 0:
                     _lib.check(rc, fn_name)
             out = dict(acts)
-            for name in plan_input_keys(self.encoder_kind):
-                out[name] = x
+            if self.obs_norm is None:
+                for name in plan_input_keys(self.encoder_kind):
+                    out[name] = x
             return out
         if not train:
             self._rec = []
         try:
-            acts = self._encode_mlp(x, train, tag) if self.encoder_kind == "mlp" else self._encode_impala(x, train, tag)
+            x_in = x
+            if self.obs_norm is not None:
+                # clamp((x - mu) / (std + eps), -5, 5) ahead of the network (rl/models.py:783-784); the net then
+                # sees a float32 input, which is also what its backward reads
+                x_in = self._buf(tag + "xn", tuple(x.shape))
+                self._call("ppo_obs_normalize_f32", _p(x), 1 if x.dtype == torch.uint8 else 0, _p(self.obs_norm.mu),
+                           _p(self.obs_norm.std), self.obs_norm.norm_eps, _p(x_in), x.shape[0], self.obs_norm.F)
+            acts = (self._encode_mlp(x_in, train, tag) if self.encoder_kind == "mlp"
+                    else self._encode_impala(x_in, train, tag))
             if self.encoder_activation_fn == "tanh":
                 h = acts["h"]
                 hact = self._buf(tag + "hact", tuple(h.shape))
@@ -810,8 +883,8 @@ class TVFModel:
                  observation_scaling: str = "scaled"):
         if architecture not in ("single", "dual"):
             raise Exception("Invalid architecture, use [dual|single]")
-        if use_rnd or observation_normalization:
-            raise NotImplementedError("RND / observation normalisation are outside the PPO hot path (DESIGN.md)")
+        if use_rnd:
+            raise NotImplementedError("RND is outside the PPO hot path (DESIGN.md)")
         if dtype != torch.float32:
             raise ValueError("the reference path is float32 (rl/models.py:31-32)")
         if observation_scaling != "scaled":
@@ -841,6 +914,12 @@ class TVFModel:
         self.policy_net = make_net()
         self.value_net = make_net() if architecture == "dual" else self.policy_net
         self.device = self.policy_net.device
+        self.observation_normalization = bool(observation_normalization)
+        self.obs_norm = None
+        if self.observation_normalization:
+            self.obs_norm = ObsNormalizer(self.input_dims, self.device, norm_eps=norm_eps,
+                                          frozen=freeze_observation_normalization)
+            self.policy_net.obs_norm = self.value_net.obs_norm = self.obs_norm
 
     def model_size(self, trainable_only: bool = True):
         n = self.policy_net.n_parameters()
@@ -861,6 +940,8 @@ class TVFModel:
                 include_features=False, update_normalization=False, **kwargs):
         assert output in ["default", "full", "policy", "value"]
         x = self.prep_for_model(x)
+        if update_normalization and self.obs_norm is not None:
+            self.obs_norm.update(x)
         net_args = dict(policy_temperature=policy_temperature, include_features=include_features, **kwargs)
 
         def public(d):
@@ -891,6 +972,22 @@ class TVFModel:
 
     def log_policy(self, x):
         return self.forward(x, output="policy")["log_policy"].detach().cpu().numpy()
+
+    @property
+    def obs_rms(self):
+        """The reference's `model.obs_rms` (utils.RunningMeanStd) as host arrays: mean / var [*input_dims] float64
+        and the scalar count."""
+        import types
+        n = self.obs_norm
+        return types.SimpleNamespace(mean=n.mean.cpu().numpy().reshape(self.input_dims),
+                                     var=n.var.cpu().numpy().reshape(self.input_dims), count=n.count)
+
+    def perform_normalization(self, x, update_normalization: bool = False):
+        """rl/models.py:666-694 on a prepared batch; returns the normalised float32 tensor."""
+        x = self.prep_for_model(x)
+        if update_normalization:
+            self.obs_norm.update(x)
+        return self.obs_norm.apply(x, torch.empty(x.shape, dtype=torch.float32, device=self.device))
 
     def adjust_value_scale(self, factor: float, process_value=True, process_tvf=True, value_net_only=False):
         """rl/models.py:630-651: scale value predictions by scaling the value / TVF head weights and biases."""

@@ -23,10 +23,16 @@ def desync_envs(runner, min_duration: int, max_duration: int, verbose=True):
         return
     A = runner.A
     steps = np.random.randint(min_duration, max_duration + 1, size=A)
-    for t in range(int(steps.max())):
+    norm = getattr(runner.model, "obs_norm", None)
+    # with observation normalisation every warm-up step also feeds the running statistics (rl/ppo.py:31), and
+    # data-parallel ranks reduce them together, so all ranks run the same number of steps
+    n_iter = int(max_duration) if norm is not None and runner.world > 1 else int(steps.max())
+    for t in range(n_iter):
+        if norm is not None:
+            norm.update(torch.from_numpy(np.ascontiguousarray(runner.obs)).to(runner.device))
         actions = np.random.randint(0, runner.n_actions, size=A).astype(np.int32)
         actions[t >= steps] = -1
-        if hasattr(runner.vec_env, "step_all"):
+        if hasattr(runner.vec_env, "step_all") and norm is None:
             runner.vec_env.step_all(actions)
         elif hasattr(runner.vec_env, "step_arrays"):
             runner.obs, _, _ = runner.vec_env.step_arrays(actions)

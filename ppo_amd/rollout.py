@@ -334,7 +334,7 @@ class Runner:
         N, A = self.N, self.A
         env = self.vec_env
         parts = getattr(env, "parts", [env])
-        if all(hasattr(p, "step_arrays") for p in parts):
+        if all(hasattr(p, "step_arrays") for p in parts) and self.model.obs_norm is None:
             self._rollout_pipelined(parts)
         else:
             self._rollout_generic(env)
@@ -412,13 +412,19 @@ class Runner:
         self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
 
     def _rollout_generic(self, env):
-        """gym-API vector env (`step(actions) -> obs, rew, done, infos`), one group."""
+        """gym-API vector env (`step(actions) -> obs, rew, done, infos`), one group.  Also the path taken with
+        observation normalisation: the running statistics are updated from ALL envs' observations of step t
+        before that step's forward, as the reference does (rl/rollout.py:735-741), which the group-pipelined
+        rollout cannot express."""
         N = self.N
+        norm = self.model.obs_norm
         rew_np, done_np = self._rewards_host.numpy(), self._dones_host.numpy()
         act_np = self._actions_host.numpy()
         stream = torch.cuda.current_stream()
         for t in range(N + 1):
             self.all_obs[t].copy_(torch.from_numpy(np.ascontiguousarray(self.obs)), non_blocking=True)
+            if norm is not None and t < N:
+                norm.update(self.all_obs[t])
             self._policy_step(t)
             if t == N:
                 break  # final state: only its value estimate is needed (rl/rollout.py:871-878)
@@ -726,6 +732,8 @@ class Runner:
             if self.dual:
                 data["value_optimizer_state_dict"] = self.value_optimizer.state_dict()
                 data["distil_optimizer_state_dict"] = self.distil_optimizer.state_dict()
+        if self.model.obs_norm is not None:
+            data["obs_rms"] = self.model.obs_norm.state_dict()  # rl/rollout.py:438-439
         if not disable_env_state and self.vec_env is not None:
             data["env_state"] = checkpoint.save_env_state(self.vec_env)
         return checkpoint.save(data, filename, bool(args.checkpoint_compression))
@@ -740,6 +748,8 @@ class Runner:
                          ("distil_optimizer_state_dict", self.distil_optimizer)):
             if opt is not None and key in cp:
                 opt.load_state_dict(cp[key])
+        if self.model.obs_norm is not None:
+            self.model.obs_norm.load_state_dict(cp["obs_rms"])  # rl/rollout.py:511-513
         self.step = cp["step"]
         self.ep_count = cp.get("ep_count", 0)
         self.batch_counter = cp.get("batch_counter", 0)

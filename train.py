@@ -35,7 +35,10 @@ def make_model(log):
         hidden_units=args.model.hidden_units,
         encoder_activation_fn="tanh" if args.env.type == "mujoco" else "relu",
         tvf_fixed_head_horizons=horizons, tvf_fixed_head_weights=weights, head_scale=args.model.head_scale,
-        head_bias=args.model.head_bias, value_head_names=("ext",))
+        head_bias=args.model.head_bias, value_head_names=("ext",),
+        observation_normalization=args.observation_normalization,
+        freeze_observation_normalization=args.freeze_observation_normalization,
+        norm_eps=args.observation_normalization_epsilon)
 
 
 def main():
