@@ -124,7 +124,7 @@ class TVFConfig(_Group):  # rl/config.py:209-246
         ("return_use_log_interpolation", bool, False, "interpolate in log-horizon space"),
         ("include_ext", bool, False, "also train the ext value head in the value phase"),
         ("trimming", str, "off", "[off]  (horizon trimming is not built)"),
-        ("head_weighting", str, "off", "[off]"),
+        ("head_weighting", str, "off", "[off|h_weighted]"),
         ("horizon_dropout", float, 0.0, "must be 0 (not built)"),
     )
 

@@ -128,6 +128,8 @@ class Runner:
             from .tvf import TVFRunnerModule
             self.tvf = TVFRunnerModule(self)
             self._tvf_weights_dev = torch.as_tensor(np.asarray(self.tvf_weights, np.float32), device=dev)
+            # value-phase weights: duplicate-head weights times the optional h_weighting (rl/tvf.py:51-62)
+            self._tvf_value_weights_dev = torch.as_tensor(self.tvf.value_loss_weights(), device=dev)
             self._ext_estimate = torch.zeros((N + 1, A), dtype=torch.float32, device=dev)
         # ---- optimisers (rl/rollout.py:126-141)
         self.policy_optimizer = Optimizer(self.policy_net, args.policy_opt)
@@ -550,7 +552,7 @@ class Runner:
         use_ext = self.tvf is None or args.tvf.include_ext
         returns = self.returns.view(B, self.VH) if use_ext else None
         tvf_returns = self.tvf.tvf_returns[:, :, :, -1].reshape(B, self.K) if self.tvf is not None else None
-        weights = self._tvf_weights_dev if self.tvf is not None else None
+        weights = self._tvf_value_weights_dev if self.tvf is not None else None
         net.zero_untouched_grads()
 
         def step(mb_obs, idx):
@@ -647,7 +649,7 @@ class Runner:
     def train_value_minibatch(self, data, loss_scale=1.0, single_value_head=None):
         if single_value_head is not None:
             raise NotImplementedError("training a single TVF head (noise-scale estimation) is out of scope")
-        weights = self._tvf_weights_dev if "tvf_returns" in data else None
+        weights = self._tvf_value_weights_dev if "tvf_returns" in data else None
         stats = self.value_net.value_minibatch(data["prev_state"], returns=data.get("returns"),
                                                tvf_returns=data.get("tvf_returns"), tvf_weights=weights,
                                                vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=loss_scale)

@@ -90,15 +90,31 @@ class TVFRunnerModule:
     def __init__(self, parent):
         import torch
         from .config import args
-        if args.tvf.trimming != "off" or args.tvf.head_weighting != "off" or args.tvf.horizon_dropout > 0:
-            raise NotImplementedError("TVF trimming / head weighting / horizon dropout are off by default and not built")
+        if args.tvf.trimming != "off" or args.tvf.horizon_dropout > 0:
+            raise NotImplementedError("TVF trimming / horizon dropout are off by default and not built")
+        if args.tvf.head_weighting not in ("off", "h_weighted"):
+            raise ValueError(f"Invalid head weighting {args.tvf.head_weighting}")
         self.runner = parent
+        self.head_weighting = args.tvf.head_weighting
         N, A, K, VH = parent.N, parent.A, len(parent.tvf_horizons), parent.VH
         dev = parent.device
         self.tvf_value = torch.zeros((N + 1, A, K, VH), dtype=torch.float32, device=dev)
         self.tvf_untrimmed_value = self.tvf_value
         self.tvf_returns = torch.zeros((N, A, K, VH), dtype=torch.float32, device=dev)
 
+    def value_loss_weights(self):
+        """Per-head weights of the value-phase TVF loss (rl/tvf.py:51-62): the duplicate-horizon weights, times —
+        with `--tvf_head_weighting=h_weighted` — 1 + (max_horizon - h) / return_n_step scaled by
+        2 / (min + max) so the loss keeps its magnitude.  float32 arithmetic as in the reference."""
+        import numpy as np
+        from .config import args
+        w = np.asarray(self.runner.tvf_weights, np.float32)
+        if self.head_weighting == "h_weighted":
+            hw = np.asarray([1 + ((args.tvf.max_horizon - h) / args.tvf_return_n_step) for h in self.runner.tvf_horizons],
+                            dtype=np.float32)
+            adjustment = 2 / (np.min(hw) + np.max(hw))
+            w = (w * hw * adjustment).astype(np.float32)
+        return w
     def calculate_tvf_returns(self, value_head: str = "ext", obs=None, rewards=None, dones=None, tvf_return_mode=None,
                               tvf_return_distribution=None, tvf_n_step=None):
         """[N, A, K] truncated return estimates for the rollout (rl/tvf.py:210-271)."""

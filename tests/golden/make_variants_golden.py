@@ -119,6 +119,14 @@ def run_variant(tag, flags, input_dims, n_actions, action_dist, activation, use_
     res = runner.train_value_minibatch(vdata, loss_scale=1.0)
     out[f"{tag}_value_result"] = np.asarray([res["loss"], res["loss_std"]], np.float64)
     record_grads(f"{tag}_value", model.value_net, m)
+    if use_tvf:
+        # the same minibatch with --tvf_head_weighting=h_weighted (rl/tvf.py:55-62)
+        args.tvf.head_weighting = "h_weighted"
+        runner.value_optimizer.zero_grad(set_to_none=True)
+        res = runner.train_value_minibatch(vdata, loss_scale=1.0)
+        out[f"{tag}_valuehw_result"] = np.asarray([res["loss"], res["loss_std"]], np.float64)
+        record_grads(f"{tag}_valuehw", model.value_net, m)
+        args.tvf.head_weighting = "off"
 
     # ---- distil phase (policy_net learns value_net's estimates under a policy constraint)
     ddata = {"prev_state": xt}

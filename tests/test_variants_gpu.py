@@ -112,6 +112,36 @@ def test_gaussian_policy_value_and_distil_minibatches():
     check_grads(pol, tag, "distil", m)
 
 
+def test_h_weighted_tvf_value_loss():
+    """--tvf_head_weighting=h_weighted (rl/tvf.py:55-62) is a per-head weight vector on the same kernel."""
+    import types
+
+    from ppo_amd import tvf
+    from ppo_amd.config import args
+    tag = "mlp_gauss_tvf"
+    model, m, _ = build(tag)
+    args.setup(["--tvf_enabled=True", "--tvf_max_horizon=1000", "--tvf_head_weighting=h_weighted"])
+    stub = types.SimpleNamespace(head_weighting="h_weighted",
+                                 runner=types.SimpleNamespace(tvf_weights=GOLD[f"{tag}_tvf_weights"],
+                                                              tvf_horizons=GOLD[f"{tag}_tvf_horizons"]))
+    w = tvf.TVFRunnerModule.value_loss_weights(stub)
+    stub.head_weighting = "off"
+    assert np.array_equal(tvf.TVFRunnerModule.value_loss_weights(stub), GOLD[f"{tag}_tvf_weights"].astype(np.float32))
+    args.setup([])
+    assert w.dtype == np.float32 and w[0] > w[-1]  # short horizons weigh more
+    val = model.value_net
+    val.grad.zero_()
+    stats = val.value_minibatch(cuda(GOLD[f"{tag}_x"]), returns=cuda(GOLD[f"{tag}_value_returns"]),
+                                tvf_returns=cuda(GOLD[f"{tag}_value_tvf_returns"]), tvf_weights=cuda(w),
+                                vf_coef=m["ppo_vf_coef"], tvf_coef=m["tvf_coef"])
+    s = stats.cpu().numpy().astype(np.float64)
+    res = GOLD[f"{tag}_valuehw_result"]
+    assert abs(res[0] - GOLD[f"{tag}_value_result"][0]) > 1e-3  # the weighting really changes the loss
+    assert abs(s[:, 2].mean() - res[0]) < 2e-6 * max(1, abs(res[0]))
+    assert abs(s[:, 2].std(ddof=1) - res[1]) < 1e-5 * max(1, abs(res[1]))
+    check_grads(val, tag, "valuehw", m)
+
+
 def test_discrete_policy_value_and_distil_minibatches():
     tag = "mlp_disc"
     model, m, _ = build(tag)
