@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_* dense peak (MI355X_MICROARCH.md, Matrix cores)
 PROBE_TRAFFIC_BYTES = int((2 * 11295 + 15009) * 1024)  # conv3x3_kernel<32,32,21,21,IN_RELU> forward, batch 256
+STACK_TAIL_TRAFFIC_BYTES = int((2 * 7826.4 + 60447.7) * 1024)  # stack_tail_kernel<32,21,21> training forward, batch 256
 SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write adv4+ret4
 FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
 
@@ -92,12 +93,14 @@ class CallProbe:
     def __init__(self, net, fn_name, match):
         self.net, self.fn_name, self.match = net, fn_name, match
         self.events = []
+        self.seen = None  # the entry point the timed launches went through
         self.enabled = False
         self._orig = net._call
         net._call = self._call
 
     def _call(self, fn_name, *a):
-        if self.enabled and fn_name in self.fn_name and self.match(a):
+        if self.enabled and fn_name in self.fn_name and self.match(fn_name, a):
+            self.seen = fn_name
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._orig(fn_name, *a)
@@ -235,9 +238,17 @@ def main():
     runner.reset()
     # dominant kernel of the step (profiles/r01e: largest total time): the 32->32 21x21 forward convolution of the
     # residual blocks, conv3x3_kernel<32,32,21,21,..,IN_RELU>; the train-minibatch launches (n == mb) are timed
-    probe = CallProbe(model.policy_net, ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32"),
-                      lambda c: c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (mb, 32, 32, 21, 21))
-    probe_flops = 2 * 9 * 32 * 32 * 21 * 21 * mb
+    # of the residual-block convolutions of the 21x21 stack: one fused launch per training forward
+    # (stack_tail_kernel<32,21,21>: 4 convolutions, image resident in LDS) or, with PPO_AMD_FUSE_STACK_TAIL=0, the
+    # individual conv3x3_kernel<32,32,21,21,IN_RELU> launches.  Only minibatch-sized training launches are timed.
+    def probe_match(fn_name, c):
+        if fn_name == "ppo_impala_stack_tail_forward_f32":  # (in, w[4], b[4], a0, q0, a1, q1, n, channels, h, w)
+            return c[3] is not None and (c[7], c[8], c[9], c[10]) == (mb, 32, 21, 21)
+        return c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (mb, 32, 32, 21, 21)
+
+    probe = CallProbe(model.policy_net, ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32",
+                                         "ppo_impala_stack_tail_forward_f32"), probe_match)
+    conv_flops = 2 * 9 * 32 * 32 * 21 * 21 * mb
 
     def iteration():
         runner.generate_rollout()
@@ -269,6 +280,17 @@ def main():
     if not probe.events:
         raise SystemExit("bench.py: the roofline probe saw no launch of its kernel (entry point renamed?)")
     kern_ms = probe.avg_ms()
+    fused = probe.seen == "ppo_impala_stack_tail_forward_f32"
+    map_bytes = 32 * 21 * 21 * 4 * mb
+    if fused:   # reads the block input, writes a0, q0, a1, q1 for the backward pass
+        probe_flops, probe_bytes, probe_traffic = 4 * conv_flops, 5 * map_bytes, STACK_TAIL_TRAFFIC_BYTES
+        probe_kernel = ("stack_tail_kernel<32,21,21> training forward: the 4 residual-block convolutions of the 21x21 "
+                        "stack in one launch (ppo_impala_stack_tail_forward_f32, minibatch launches)")
+        probe_source = "profiles/r01l_stack_tail_hbm_traffic.md"
+    else:
+        probe_flops, probe_bytes, probe_traffic = conv_flops, 2 * map_bytes, PROBE_TRAFFIC_BYTES
+        probe_kernel = "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)"
+        probe_source = "profiles/r01j_conv_hbm_traffic.md"
     tflops = probe_flops / (kern_ms * 1e-3) / 1e12
     samples_fwd = (N + 1) * A + args.policy_opt.epochs * N * A
     samples_bwd = args.policy_opt.epochs * N * A
@@ -297,10 +319,10 @@ def main():
                      # separate passes over tools/conv_tune (counter collection around the whole PPO iteration
                      # segfaults in rocprofv3 on this pool), 2 x FETCH_SIZE + WRITE_SIZE KiB as the guide prescribes
                      # for gfx950; algorithmic = input + output = 28.9 MB, the 8/6 halo-row re-read accounts for the rest
-                     "traffic": PROBE_TRAFFIC_BYTES if mb == 256 else None,
-                     "traffic_source": "profiles/r01j_conv_hbm_traffic.md",
-                     "algorithmic_bytes_per_launch": 2 * 32 * 21 * 21 * 4 * mb,
-                     "kernel": "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)",
+                     "traffic": probe_traffic if mb == 256 else None,
+                     "traffic_source": probe_source,
+                     "algorithmic_bytes_per_launch": probe_bytes,
+                     "kernel": probe_kernel,
                      "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
                      "launches_timed": len(probe.events)},
         "phase_seconds_per_step": {k: round(v / a.steps, 4) for k, v in phase.items()},

@@ -354,6 +354,20 @@ int ppo_tvf_returns_f32(const float *rewards, const uint8_t *dones, const float 
                         size_t workspace_bytes, float *out, void *stream);
 
 /* ------------------------------------------------------------------------
+ * The two residual blocks of an IMPALA stack as one launch, image resident in LDS
+ * (rl/impala.py:66-84 ImpalaResidualBlock.forward x 2, :110-114):
+ *   a0 = conv0_0(relu(in)) + b;  q0 = in + conv1_0(relu(a0)) + b;  a1 = conv0_1(relu(q0)) + b;  q1 = q0 + conv1_1(relu(a1)) + b
+ * packed_weights / biases: HOST arrays of 4 device pointers (block0.conv0, block0.conv1, block1.conv0,
+ * block1.conv1; weights in the forward packed layout of ppo_conv3x3_pack_weights_f32).  a0, q0, a1 are nullable
+ * (inference: only q1 is written).  Results are bit-identical to four ppo_conv3x3_forward_packed_f32 calls.
+ * ppo_impala_stack_tail_supported tells whether a (channels, h, w) geometry has a kernel (32 @ 11x11).
+ * ---------------------------------------------------------------------- */
+int ppo_impala_stack_tail_supported(int channels, int h, int w);
+int ppo_impala_stack_tail_forward_f32(const float *in, const float *const *packed_weights, const float *const *biases,
+                                      float *a0, float *q0, float *a1, float *q1, int n_images, int channels, int h,
+                                      int w, void *stream);
+
+/* ------------------------------------------------------------------------
  * Observation normalisation (`--observation_normalization`, rl/models.py:661-694): running per-feature
  * mean / variance (utils.RunningMeanStd, rl/utils.py:379-455) kept on the device in float64, and the
  * transform clamp((x - mu) / (std + eps), -5, 5) applied to the prepared observation (uint8 -> x/255,

@@ -1,0 +1,243 @@
+// The residual blocks of an IMPALA stack as ONE kernel with the image resident in LDS (gfx950).
+//
+//   q0 = p  + conv1_0(relu(conv0_0(relu(p))))        (rl/impala.py:66-84, ImpalaResidualBlock.forward)
+//   q1 = q0 + conv1_1(relu(conv0_1(relu(q0))))       (rl/impala.py:110-114: two blocks per stack)
+//
+// Why: at a minibatch of 256 every launch on the forward's dependent chain costs ~10 us whatever it computes
+// (kernel boundary, weight prologue, first band, tail), and the four 32->32 convolutions of the
+// 11x11 stack compute for under 4 us each.  A 32-channel 11x11 map is 15 KB, so a workgroup keeps its image in LDS
+// across all four convolutions: no cross-workgroup exchange, no kernel boundary, intermediate maps go to HBM only
+// when the backward pass needs them (training) and are never read back.
+//
+// Per image: X <- p (LDS-DMA);  Y = conv(relu(X));  X += conv(relu(Y));  Y = conv(relu(X));  X += conv(relu(Y)).
+// Each convolution is the implicit GEMM of conv3x3.hip (same flat band layout with TR = H, same K order, same
+// epilogue arithmetic: results are bit-identical to the four separate launches); its weights are the pre-packed A
+// operand (ppo_conv3x3_pack_weights_f32), re-loaded into registers at each layer switch.
+#include "common.h"
+#include "conv_stage.h"
+#include "mfma.h"
+
+namespace ppo {
+namespace {
+
+struct StackTailArgs {
+    const float *in;       // [n, C, H, W] block input p
+    const float *w[4];     // packed weights: block0.conv0, block0.conv1, block1.conv0, block1.conv1
+    const float *bias[4];
+    float *save[4];        // a0, q0, a1, q1 ([n, C, H, W] each); q1 is required, the others nullable (inference)
+    int n_images;
+};
+
+template <int C, int H, int W, int MT, int NW>
+struct StackCfg {
+    static constexpr int ROWS = H + 2;
+    static constexpr int G = 4;
+    static constexpr int PLANE_RAW = ROWS * W + 2 * G;
+    static constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;  // = 16 (mod 32)
+    static constexpr int NT = C / 16;
+    static constexpr int KS = 9 * (C / 4);
+    static constexpr int NPIX = H * W;
+    static constexpr int MTILES = (NPIX + 15) / 16;
+    static constexpr int LDS_MAP = C * PLANE;  // floats per resident map
+    static constexpr size_t LDS_BYTES = (size_t)2 * LDS_MAP * 4;
+    static_assert(C % 16 == 0, "channel tiles of 16");
+    static_assert(MTILES == MT * NW, "one group of MT pixel tiles per wave");
+};
+
+template <int C, int H, int W, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
+{
+    using S = StackCfg<C, H, W, MT, NW>;
+    constexpr int NT = S::NT, KS = S::KS, PLANE = S::PLANE, G = S::G;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+
+    zero_lds<2 * S::LDS_MAP, NW * 64>(smem, tid);  // guards and halo rows of both maps stay zero
+    __syncthreads();
+
+    int pix[MT], lofs[MT];
+    float hi_l[MT], hi_r[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = (wave * MT + m) * 16 + l15;
+        pix[m] = p;
+        const int pc = p < S::NPIX ? p : 0;
+        lofs[m] = G + pc - 1 + g * PLANE;
+        hi_l[m] = (pc % W == 0) ? 0.f : INFINITY;
+        hi_r[m] = (pc % W == W - 1) ? 0.f : INFINITY;
+    }
+
+    for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
+        __syncthreads();  // the previous image's last readers of X are done
+        stage_band_chunk_dma<C, H, W, S::ROWS, PLANE, G, NW>(a.in, img, 0, smem, tid);
+        const size_t img_off = (size_t)img * C * H * W;
+
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            // ---- this layer's A operand and bias: 16-byte coalesced loads, in flight across the barrier below
+            float wa[NT][KS];
+            const float4 *pw = reinterpret_cast<const float4 *>(a.w[layer]);
+#pragma unroll
+            for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 v = pw[(s4 * NT + n) * 64 + lane];
+                    wa[n][4 * s4 + 0] = v.x;
+                    wa[n][4 * s4 + 1] = v.y;
+                    wa[n][4 * s4 + 2] = v.z;
+                    wa[n][4 * s4 + 3] = v.w;
+                }
+            float bias_r[NT][4];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias_r[n][r] = a.bias[layer][n * 16 + g * 4 + r];
+
+            __syncthreads();  // the source map is complete (DMA landed / previous epilogue's LDS writes)
+            const int odd = layer & 1;
+            const int src = odd ? S::LDS_MAP : 0;  // even layers read X, odd layers read Y
+            int base[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) base[m] = lofs[m] + src;
+
+            f32x4 acc[NT][MT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            // K loop: the forward block pipeline of conv3x3.hip (ReLU on read, edge taps masked by the same med3)
+            constexpr int SB = (MT * NT >= 4) ? 2 : 4;
+            constexpr int NB = (KS + SB - 1) / SB;
+            float raw[2][SB][MT];
+            auto load_block = [&](int j, float (&r)[SB][MT]) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int s = j * SB + u;
+                    if (s < KS) {
+                        const int tap = s / (C / 4), cs = s % (C / 4);
+                        const int tap_off = (tap / 3) * W + (tap % 3);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) r[u][m] = smem[base[m] + cs * 4 * PLANE + tap_off];
+                    }
+                }
+            };
+            load_block(0, raw[0]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float bv[SB][MT];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int s = j * SB + u;
+                    if (s < KS) {
+                        const int kx = (s / (C / 4)) % 3;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            float x = raw[j & 1][u][m];
+                            if (kx != 1)
+                                x = __builtin_amdgcn_fmed3f(x, 0.f, kx == 0 ? hi_l[m] : hi_r[m]);
+                            else
+                                x = relu1(x);
+                            bv[u][m] = x;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < NB) load_block(j + 1, raw[(j + 1) & 1]);
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int s = j * SB + u;
+                    if (s < KS) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(wa[n][s], bv[u][m], acc[n][m]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // ---- epilogue: lane holds pixel l15 x channels g*4..g*4+3 of each tile.  Even layers write Y, odd layers
+            // add the block input (X, same positions) and overwrite it: nobody else reads those positions of X
+            // during an odd layer, and the next layer's readers wait at its barrier.
+            float *dst = smem + (odd ? 0 : S::LDS_MAP);
+            float *save = a.save[layer];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (pix[m] < S::NPIX) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = n * 16 + g * 4 + r;
+                            const int lo = co * PLANE + G + W + pix[m];
+                            float val = acc[n][m][r] + bias_r[n][r];
+                            if (odd) val = val + smem[lo];
+                            dst[lo] = val;
+                            if (save) save[img_off + (size_t)co * (H * W) + pix[m]] = val;
+                        }
+                }
+            }
+        }
+    }
+}
+
+template <int C, int H, int W, int MT, int NW>
+int launch_stack_tail(const StackTailArgs &args, hipStream_t st)
+{
+    using S = StackCfg<C, H, W, MT, NW>;
+    auto kern = stack_tail_kernel<C, H, W, MT, NW>;
+    static int wg_per_cu = 0;
+    if (wg_per_cu == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)S::LDS_BYTES);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, S::LDS_BYTES);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_tail: occupancy query: %s", hipGetErrorString(e));
+        wg_per_cu = nb < 1 ? 1 : nb;
+    }
+    int grid = 256 * wg_per_cu;
+    if (grid > args.n_images) grid = args.n_images;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), S::LDS_BYTES, st, args);
+    return check_launch("stack_tail_kernel");
+}
+
+}  // namespace
+}  // namespace ppo
+
+extern "C" int ppo_impala_stack_tail_supported(int channels, int h, int w)
+{
+    return channels == 32 && ((h == 11 && w == 11) || (h == 21 && w == 21));
+}
+
+extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *const *packed_weights,
+                                                 const float *const *biases, float *a0, float *q0, float *a1, float *q1,
+                                                 int n_images, int channels, int h, int w, void *stream)
+{
+    using namespace ppo;
+    if (n_images < 0) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: negative batch");
+    if (n_images == 0) return PPO_OK;
+    if (!in || !packed_weights || !biases || !q1)
+        return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: null pointer");
+    StackTailArgs args;
+    args.in = in;
+    for (int l = 0; l < 4; ++l) {
+        if (!packed_weights[l] || !biases[l])
+            return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: null weights / bias of layer %d", l);
+        if (!aligned(packed_weights[l], 16))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_forward_f32: packed weights must be 16-byte aligned");
+        args.w[l] = packed_weights[l];
+        args.bias[l] = biases[l];
+    }
+    if (!aligned(in, 4)) return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_forward_f32: input must be 4-byte aligned");
+    args.save[0] = a0;
+    args.save[1] = q0;
+    args.save[2] = a1;
+    args.save[3] = q1;
+    args.n_images = n_images;
+    hipStream_t st = as_stream(stream);
+    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4>(args, st);
+    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4>(args, st);
+    return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+}

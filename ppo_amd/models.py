@@ -34,6 +34,9 @@ WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
+# The two residual blocks of a stack as one launch with the image resident in LDS (csrc/stack_fused.hip), where the
+# geometry has a kernel (32 channels at 11x11) and the packed weights exist; 0 = four convolution launches.
+FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -278,6 +281,7 @@ class DualHeadNet:
         self._build_parameters(head_scale)
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._rec = None   # launch recorder (see encode)
+        self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self._build_packed_weights()
@@ -516,6 +520,23 @@ class DualHeadNet:
         self._linear(a1, sp.hidden_units, "encoder.fc2", h, tag=tag)
         return {"x": x, "a1": a1, "h": h}
 
+    def _stack_tail_ptrs(self, si, cout, ho, wo):
+        """Host arrays of the four packed-weight / bias pointers of stack si's residual blocks for the fused
+        kernel, or None when it does not apply.  The arrays are cached: packed buffers and parameter views keep
+        their addresses for the life of the net."""
+        if not FUSE_STACK_TAIL or self.spec.n_block != 2 or not self.lib.ppo_impala_stack_tail_supported(cout, ho, wo):
+            return None
+        cached = self._tail_ptrs.get(si)
+        if cached is None:
+            names = [f"encoder.stacks.{si}.blocks.{bi}.conv{ci}" for bi in range(2) for ci in range(2)]
+            pks = [self._pk.get((n, 0)) for n in names]
+            if any(pk is None for pk in pks):
+                return None
+            cached = ((ctypes.c_void_p * 4)(*[pk.data_ptr() for pk in pks]),
+                      (ctypes.c_void_p * 4)(*[self.params[n + ".bias"].data_ptr() for n in names]))
+            self._tail_ptrs[si] = cached
+        return cached
+
     def _encode_impala(self, x, train, tag):
         sp = self.spec
         B = x.shape[0]
@@ -537,6 +558,16 @@ class DualHeadNet:
                 self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
             acts[f"in{si}"], acts[f"idx{si}"] = cur, idx
             q = p
+            tail = self._stack_tail_ptrs(si, cout, ho, wo)
+            if tail is not None:
+                names = [f"{tag}a{si}_0", f"{tag}q{si}_0", f"{tag}a{si}_1", f"{tag}q{si}_1"]
+                a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
+                # inference needs only the stack's output; training keeps the maps the backward pass reads
+                self._call("ppo_impala_stack_tail_forward_f32", _p(p), tail[0], tail[1], _p(a0) if train else None,
+                           _p(q0) if train else None, _p(a1) if train else None, _p(q1), B, cout, ho, wo)
+                acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"] = p, a0, q0, a1
+                cur, cur_mode = q1, IN_NONE
+                continue
             for bi in range(sp.n_block):
                 a = self._buf(f"{tag}a{si}_{bi}", (B, cout, ho, wo))
                 qn = self._buf(f"{tag}q{si}_{bi}", (B, cout, ho, wo))

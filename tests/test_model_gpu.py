@@ -162,3 +162,45 @@ def test_state_dict_round_trip(gold):
     assert list(a.state_dict())[0] == "log_std"
     with pytest.raises(KeyError):
         b.load_state_dict({"nope": torch.zeros(1)})
+
+
+def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
+    """csrc/stack_fused.hip: the two residual blocks of the 11x11 stack in one launch (image resident in LDS) give
+    the same bits as the four convolution launches — inference rows, the saved maps of a training forward, and every
+    gradient of a PPO minibatch — at ragged batch sizes too."""
+    from ppo_amd import models
+    torch.manual_seed(3)
+    dims, nA = (4, 84, 84), 6
+    monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
+    a = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
+    assert a.lib.ppo_impala_stack_tail_supported(32, 11, 11) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 21, 21) == 1
+    assert a.lib.ppo_impala_stack_tail_supported(16, 42, 42) == 0
+    b = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for B in (1, 37, 256, 300):
+        x = torch.randint(0, 256, (B, *dims), dtype=torch.uint8, device="cuda", generator=g)
+        for _ in range(2):  # the second pass replays the recorded launch plan
+            monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
+            ha = a.forward(x)["_heads"].clone()
+            assert sorted(a._tail_ptrs) == [1, 2], "the fused path did not engage for both 32-channel stacks"
+            monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
+            hb = b.forward(x)["_heads"].clone()
+            assert not b._tail_ptrs
+            assert torch.equal(ha, hb), B
+        actions = torch.randint(0, nA, (B,), dtype=torch.int32, device="cuda", generator=g)
+        logp = torch.log_softmax(torch.randn(B, nA, device="cuda", generator=g), dim=1)
+        pac = logp.gather(1, actions.long()[:, None])[:, 0].contiguous()
+        adv, ret = torch.randn(B, device="cuda", generator=g), torch.randn(B, 1, device="cuda", generator=g)
+        monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
+        acts_a = a.encode(x, train=True)
+        saved = {k: acts_a[k].clone() for k in ("q1_0_in", "a1_0", "q1_1_in", "a1_1", "in2",
+                                                "q2_0_in", "a2_0", "q2_1_in", "a2_1", "flat")}
+        a.ppo_minibatch(x, actions, pac, logp, adv, ret)
+        monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
+        acts_b = b.encode(x, train=True)
+        for k, v in saved.items():
+            assert torch.equal(v, acts_b[k]), (B, k)
+        b.ppo_minibatch(x, actions, pac, logp, adv, ret)
+        torch.cuda.synchronize()
+        assert torch.equal(a.grad, b.grad) and float(a.grad.abs().sum()) > 0, B
