@@ -366,6 +366,17 @@ int ppo_impala_stack_tail_supported(int channels, int h, int w);
 int ppo_impala_stack_tail_forward_f32(const float *in, const float *const *packed_weights, const float *const *biases,
                                       float *a0, float *q0, float *a1, float *q1, int n_images, int channels, int h,
                                       int w, void *stream);
+/*
+ * Backward-data of the same two blocks in one launch (the transposed chain of ppo_conv3x3_backward_data_packed_f32 x 4):
+ *   da1 = conv1_1^T(g) * [a1 > 0];  g1 = g + conv0_1^T(da1) * [q0 > 0];
+ *   da0 = conv1_0^T(g1) * [a0 > 0]; g0 = g1 + conv0_0^T(da0) * [p > 0]
+ * g = d loss / d q1.  packed_weights_t: HOST array of the 4 backward-data packed weights in PROCESSING order
+ * (block1.conv1, block1.conv0, block0.conv1, block0.conv0); masks: HOST array of the 4 forward pre-activation
+ * maps in the same order (a1, q0, a0, p).  All four outputs are written (the weight gradients read them).
+ */
+int ppo_impala_stack_tail_backward_f32(const float *g, const float *const *packed_weights_t, const float *const *masks,
+                                       float *da1, float *g1, float *da0, float *g0, int n_images, int channels,
+                                       int h, int w, void *stream);
 
 /* ------------------------------------------------------------------------
  * Observation normalisation (`--observation_normalization`, rl/models.py:661-694): running per-feature

@@ -9,6 +9,11 @@
 // across all four convolutions: no cross-workgroup exchange, no kernel boundary, intermediate maps go to HBM only
 // when the backward pass needs them (training) and are never read back.
 //
+// The backward-data pass of the same blocks is the same kernel with the flipped / transposed packed weights, no ReLU
+// on read, and each layer's output gated by its forward pre-activation:
+//   da1 = conv1_1^T(g) * [a1 > 0];  g1 = g + conv0_1^T(da1) * [q0 > 0];  da0 = conv1_0^T(g1) * [a0 > 0];
+//   g0 = g1 + conv0_0^T(da0) * [p > 0]                       (all four are written: the weight gradients read them)
+//
 // Per image: X <- p (LDS-DMA);  Y = conv(relu(X));  X += conv(relu(Y));  Y = conv(relu(X));  X += conv(relu(Y)).
 // Each convolution is the implicit GEMM of conv3x3.hip (same flat band layout with TR = H, same K order, same
 // epilogue arithmetic: results are bit-identical to the four separate launches); its weights are the pre-packed A
@@ -23,8 +28,10 @@ namespace {
 struct StackTailArgs {
     const float *in;       // [n, C, H, W] block input p
     const float *w[4];     // packed weights: block0.conv0, block0.conv1, block1.conv0, block1.conv1
-    const float *bias[4];
-    float *save[4];        // a0, q0, a1, q1 ([n, C, H, W] each); q1 is required, the others nullable (inference)
+    const float *bias[4];  // forward only
+    const float *mask[4];  // backward only: pre-activation map gating each layer's output ([n, C, H, W])
+    float *save[4];        // forward: a0, q0, a1, q1 ([n, C, H, W] each); the last is required, the others nullable
+                           // backward: da1, dq1_in, da0, dq0_in (all required: the weight gradients read them)
     int n_images;
 };
 
@@ -44,7 +51,7 @@ struct StackCfg {
     static_assert(MTILES == MT * NW, "one group of MT pixel tiles per wave");
 };
 
-template <int C, int H, int W, int MT, int NW>
+template <int C, int H, int W, int MT, int NW, bool BACKWARD>
 __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
 {
     using S = StackCfg<C, H, W, MT, NW>;
@@ -91,7 +98,20 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bias_r[n][r] = a.bias[layer][n * 16 + g * 4 + r];
+                for (int r = 0; r < 4; ++r) bias_r[n][r] = BACKWARD ? 0.f : a.bias[layer][n * 16 + g * 4 + r];
+            // backward: the ReLU gate of this layer's output (its forward pre-activation), requested now and consumed
+            // after the K loop
+            float gate[BACKWARD ? MT : 1][NT][4];
+            if constexpr (BACKWARD) {
+                const float *mask = a.mask[layer] + img_off;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            gate[m][n][r] = pix[m] < S::NPIX ? mask[(n * 16 + g * 4 + r) * (H * W) + pix[m]] : 1.f;
+            }
 
             __syncthreads();  // the source map is complete (DMA landed / previous epilogue's LDS writes)
             const int odd = layer & 1;
@@ -134,10 +154,12 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
                             float x = raw[j & 1][u][m];
-                            if (kx != 1)
-                                x = __builtin_amdgcn_fmed3f(x, 0.f, kx == 0 ? hi_l[m] : hi_r[m]);
-                            else
+                            if (kx != 1) {
+                                const float hi = kx == 0 ? hi_l[m] : hi_r[m];
+                                x = __builtin_amdgcn_fmed3f(x, BACKWARD ? -hi : 0.f, hi);
+                            } else if (!BACKWARD) {
                                 x = relu1(x);
+                            }
                             bv[u][m] = x;
                         }
                     }
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
                             const int co = n * 16 + g * 4 + r;
                             const int lo = co * PLANE + G + W + pix[m];
                             float val = acc[n][m][r] + bias_r[n][r];
+                            if constexpr (BACKWARD) val = gate[m][n][r] > 0.f ? val : 0.f;
                             if (odd) val = val + smem[lo];
                             dst[lo] = val;
                             if (save) save[img_off + (size_t)co * (H * W) + pix[m]] = val;
@@ -182,11 +205,11 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
     }
 }
 
-template <int C, int H, int W, int MT, int NW>
+template <int C, int H, int W, int MT, int NW, bool BACKWARD>
 int launch_stack_tail(const StackTailArgs &args, hipStream_t st)
 {
     using S = StackCfg<C, H, W, MT, NW>;
-    auto kern = stack_tail_kernel<C, H, W, MT, NW>;
+    auto kern = stack_tail_kernel<C, H, W, MT, NW, BACKWARD>;
     static int wg_per_cu = 0;
     if (wg_per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -229,6 +252,7 @@ extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *c
             return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_forward_f32: packed weights must be 16-byte aligned");
         args.w[l] = packed_weights[l];
         args.bias[l] = biases[l];
+        args.mask[l] = nullptr;
     }
     if (!aligned(in, 4)) return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_forward_f32: input must be 4-byte aligned");
     args.save[0] = a0;
@@ -237,7 +261,38 @@ extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *c
     args.save[3] = q1;
     args.n_images = n_images;
     hipStream_t st = as_stream(stream);
-    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4>(args, st);
-    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4>(args, st);
+    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, false>(args, st);
+    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, false>(args, st);
     return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+}
+
+extern "C" int ppo_impala_stack_tail_backward_f32(const float *g, const float *const *packed_weights_t,
+                                                  const float *const *masks, float *da1, float *g1, float *da0, float *g0,
+                                                  int n_images, int channels, int h, int w, void *stream)
+{
+    using namespace ppo;
+    if (n_images < 0) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: negative batch");
+    if (n_images == 0) return PPO_OK;
+    if (!g || !packed_weights_t || !masks || !da1 || !g1 || !da0 || !g0)
+        return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: null pointer");
+    StackTailArgs args;
+    args.in = g;
+    for (int l = 0; l < 4; ++l) {
+        if (!packed_weights_t[l] || !masks[l])
+            return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: null weights / mask of layer %d", l);
+        if (!aligned(packed_weights_t[l], 16))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_backward_f32: packed weights must be 16-byte aligned");
+        args.w[l] = packed_weights_t[l];
+        args.bias[l] = nullptr;
+        args.mask[l] = masks[l];
+    }
+    args.save[0] = da1;
+    args.save[1] = g1;
+    args.save[2] = da0;
+    args.save[3] = g0;
+    args.n_images = n_images;
+    hipStream_t st = as_stream(stream);
+    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, true>(args, st);
+    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, true>(args, st);
+    return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }

@@ -37,6 +37,11 @@ PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
 # The two residual blocks of a stack as one launch with the image resident in LDS (csrc/stack_fused.hip), where the
 # geometry has a kernel (32 channels at 11x11) and the packed weights exist; 0 = four convolution launches.
 FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
+# ... and the same for their backward-data chain, as a bit mask over the stacks.  Default: the 11x11 stack only.  The
+# 21x21 chain measures neutral to slightly slower fused (1.473 ms per 256-sample step with mask 4, 1.479 with 2,
+# 1.493 with 6, 1.485 with 0): its one-workgroup-per-CU kernel leaves the weight-gradient stream nothing to overlap
+# with and releases the three gradients those kernels wait for only at its end.
+FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "4"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -736,7 +741,22 @@ class DualHeadNet:
 
         for si in reversed(range(len(sp.stacks))):
             cin, cout, hh, ww, ho, wo = sp.stacks[si]
-            for bi in reversed(range(sp.n_block)):
+            tail_w = self._stack_tail_bwd_ptrs(si, cout, ho, wo)
+            if tail_w is not None:
+                # the four backward-data convolutions of the stack's blocks in one launch (csrc/stack_fused.hip)
+                b0, b1 = f"encoder.stacks.{si}.blocks.0", f"encoder.stacks.{si}.blocks.1"
+                p_in, a0, q0, a1 = acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"]
+                da1, g1, da0, g0 = (self._buf(nm, (B, cout, ho, wo)) for nm in
+                                    (f"g{si}_1_da", f"g{si}_1_in", f"g{si}_0_da", f"g{si}_0_in"))
+                wgrad(a1, IN_RELU, g, b1 + ".conv1", B, cout, cout, ho, wo)  # its dy is the incoming gradient
+                masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p_in.data_ptr())
+                self._call("ppo_impala_stack_tail_backward_f32", _p(g), tail_w, masks, _p(da1), _p(g1), _p(da0), _p(g0),
+                           B, cout, ho, wo)
+                wgrad(q0, IN_RELU, da1, b1 + ".conv0", B, cout, cout, ho, wo)
+                wgrad(a0, IN_RELU, g1, b0 + ".conv1", B, cout, cout, ho, wo)
+                wgrad(p_in, IN_RELU, da0, b0 + ".conv0", B, cout, cout, ho, wo)
+                g = g0
+            for bi in (reversed(range(sp.n_block)) if tail_w is None else ()):
                 base = f"encoder.stacks.{si}.blocks.{bi}"
                 q_in, a = acts[f"q{si}_{bi}_in"], acts[f"a{si}_{bi}"]
                 # g = d loss / d (block output);  block: out = q_in + conv1(relu(conv0(relu(q_in))))
@@ -769,6 +789,22 @@ class DualHeadNet:
                     self._call("ppo_conv3x3_wgrad_reduce_f32", ctypes.addressof(table), len(jobs))
         if side is not None:
             main.wait_stream(side)  # all weight gradients are in self.grad before anything reads it
+
+    def _stack_tail_bwd_ptrs(self, si, cout, ho, wo):
+        """Host array of the four backward-data packed weights of stack si's blocks in processing order
+        (block1.conv1, block1.conv0, block0.conv1, block0.conv0), or None when the fused kernel does not apply."""
+        if not (FUSE_STACK_TAIL and FUSE_STACK_TAIL_BWD >> si & 1) or self.spec.n_block != 2 \
+                or not self.lib.ppo_impala_stack_tail_supported(cout, ho, wo):
+            return None
+        cached = self._tail_ptrs.get(("bwd", si))
+        if cached is None:
+            names = [f"encoder.stacks.{si}.blocks.{bi}.conv{ci}" for bi in (1, 0) for ci in (1, 0)]
+            pks = [self._pk.get((n, 1)) for n in names]
+            if any(pk is None for pk in pks):
+                return None
+            cached = (ctypes.c_void_p * 4)(*[pk.data_ptr() for pk in pks])
+            self._tail_ptrs[("bwd", si)] = cached
+        return cached
 
     def _bwd_data_fn(self, wname):
         return "ppo_conv3x3_backward_data_packed_f32" if (wname, 1) in self._pk else "ppo_conv3x3_backward_data_f32"
