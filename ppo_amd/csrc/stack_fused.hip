@@ -22,6 +22,12 @@
 #include "conv_stage.h"
 #include "mfma.h"
 
+// Channel-tile groups per workgroup (see StackCfg).  Measured: 2 -> forward 0.458 ms and train step 1.41 ms per 256
+// samples, 1 -> 0.465 / 1.44.
+#ifndef PPO_TAIL_SPLIT
+#define PPO_TAIL_SPLIT 2
+#endif
+
 namespace ppo {
 namespace {
 
@@ -35,13 +41,18 @@ struct StackTailArgs {
     int n_images;
 };
 
-template <int C, int H, int W, int MT, int NW>
+// NW pixel-tile waves x NSPLIT channel-tile groups: wave = ng * NW + pw computes MT pixel tiles x NT / NSPLIT channel
+// tiles.  NSPLIT = 2 puts two waves on every SIMD of the CU the image owns, so one wave's operand reads, med3s and
+// epilogue issue under the other's MFMAs.
+template <int C, int H, int W, int MT, int NW, int NSPLIT>
 struct StackCfg {
     static constexpr int ROWS = H + 2;
     static constexpr int G = 4;
     static constexpr int PLANE_RAW = ROWS * W + 2 * G;
     static constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;  // = 16 (mod 32)
-    static constexpr int NT = C / 16;
+    static constexpr int NT = C / 16;            // channel tiles of the layer
+    static constexpr int NTL = NT / NSPLIT;      // ... of one wave
+    static constexpr int WAVES = NW * NSPLIT;
     static constexpr int KS = 9 * (C / 4);
     static constexpr int NPIX = H * W;
     static constexpr int MTILES = (NPIX + 15) / 16;
@@ -49,17 +60,20 @@ struct StackCfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * LDS_MAP * 4;
     static_assert(C % 16 == 0, "channel tiles of 16");
     static_assert(MTILES == MT * NW, "one group of MT pixel tiles per wave");
+    static_assert(NT % NSPLIT == 0, "channel tiles split evenly");
 };
 
-template <int C, int H, int W, int MT, int NW, bool BACKWARD>
-__global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
+template <int C, int H, int W, int MT, int NW, int NSPLIT, bool BACKWARD>
+__global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailArgs a)
 {
-    using S = StackCfg<C, H, W, MT, NW>;
-    constexpr int NT = S::NT, KS = S::KS, PLANE = S::PLANE, G = S::G;
+    using S = StackCfg<C, H, W, MT, NW, NSPLIT>;
+    constexpr int NT = S::NTL, KS = S::KS, PLANE = S::PLANE, G = S::G;
     extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = (tid >> 6) % NW;        // pixel-tile group
+    const int n0 = ((tid >> 6) / NW) * NT;   // first channel tile of this wave
 
-    zero_lds<2 * S::LDS_MAP, NW * 64>(smem, tid);  // guards and halo rows of both maps stay zero
+    zero_lds<2 * S::LDS_MAP, S::WAVES * 64>(smem, tid);  // guards and halo rows of both maps stay zero
     __syncthreads();
 
     int pix[MT], lofs[MT];
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
 
     for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
         __syncthreads();  // the previous image's last readers of X are done
-        stage_band_chunk_dma<C, H, W, S::ROWS, PLANE, G, NW>(a.in, img, 0, smem, tid);
+        stage_band_chunk_dma<C, H, W, S::ROWS, PLANE, G, S::WAVES>(a.in, img, 0, smem, tid);
         const size_t img_off = (size_t)img * C * H * W;
 
 #pragma unroll 1
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
             for (int s4 = 0; s4 < KS / 4; ++s4)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const float4 v = pw[(s4 * NT + n) * 64 + lane];
+                    const float4 v = pw[(s4 * S::NT + n0 + n) * 64 + lane];
                     wa[n][4 * s4 + 0] = v.x;
                     wa[n][4 * s4 + 1] = v.y;
                     wa[n][4 * s4 + 2] = v.z;
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bias_r[n][r] = BACKWARD ? 0.f : a.bias[layer][n * 16 + g * 4 + r];
+                for (int r = 0; r < 4; ++r) bias_r[n][r] = BACKWARD ? 0.f : a.bias[layer][(n0 + n) * 16 + g * 4 + r];
             // backward: the ReLU gate of this layer's output (its forward pre-activation), requested now and consumed
             // after the K loop
             float gate[BACKWARD ? MT : 1][NT][4];
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            gate[m][n][r] = pix[m] < S::NPIX ? mask[(n * 16 + g * 4 + r) * (H * W) + pix[m]] : 1.f;
+                            gate[m][n][r] = pix[m] < S::NPIX ? mask[((n0 + n) * 16 + g * 4 + r) * (H * W) + pix[m]] : 1.f;
             }
 
             __syncthreads();  // the source map is complete (DMA landed / previous epilogue's LDS writes)
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int co = n * 16 + g * 4 + r;
+                            const int co = (n0 + n) * 16 + g * 4 + r;
                             const int lo = co * PLANE + G + W + pix[m];
                             float val = acc[n][m][r] + bias_r[n][r];
                             if constexpr (BACKWARD) val = gate[m][n][r] > 0.f ? val : 0.f;
@@ -205,24 +219,24 @@ __global__ __launch_bounds__(NW * 64) void stack_tail_kernel(StackTailArgs a)
     }
 }
 
-template <int C, int H, int W, int MT, int NW, bool BACKWARD>
+template <int C, int H, int W, int MT, int NW, int NSPLIT, bool BACKWARD>
 int launch_stack_tail(const StackTailArgs &args, hipStream_t st)
 {
-    using S = StackCfg<C, H, W, MT, NW>;
-    auto kern = stack_tail_kernel<C, H, W, MT, NW, BACKWARD>;
+    using S = StackCfg<C, H, W, MT, NW, NSPLIT>;
+    auto kern = stack_tail_kernel<C, H, W, MT, NW, NSPLIT, BACKWARD>;
     static int wg_per_cu = 0;
     if (wg_per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)S::LDS_BYTES);
         if (e != hipSuccess) return fail(PPO_E_HIP, "stack_tail: hipFuncSetAttribute: %s", hipGetErrorString(e));
         int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, S::LDS_BYTES);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, S::WAVES * 64, S::LDS_BYTES);
         if (e != hipSuccess) return fail(PPO_E_HIP, "stack_tail: occupancy query: %s", hipGetErrorString(e));
         wg_per_cu = nb < 1 ? 1 : nb;
     }
     int grid = 256 * wg_per_cu;
     if (grid > args.n_images) grid = args.n_images;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), S::LDS_BYTES, st, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(S::WAVES * 64), S::LDS_BYTES, st, args);
     return check_launch("stack_tail_kernel");
 }
 
@@ -261,8 +275,8 @@ extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *c
     args.save[3] = q1;
     args.n_images = n_images;
     hipStream_t st = as_stream(stream);
-    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, false>(args, st);
-    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, false>(args, st);
+    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, false>(args, st);
+    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, false>(args, st);
     return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }
 
@@ -292,7 +306,7 @@ extern "C" int ppo_impala_stack_tail_backward_f32(const float *g, const float *c
     args.save[3] = g0;
     args.n_images = n_images;
     hipStream_t st = as_stream(stream);
-    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, true>(args, st);
-    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, true>(args, st);
+    if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, true>(args, st);
+    if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, true>(args, st);
     return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }

@@ -37,11 +37,9 @@ PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
 # The two residual blocks of a stack as one launch with the image resident in LDS (csrc/stack_fused.hip), where the
 # geometry has a kernel (32 channels at 11x11) and the packed weights exist; 0 = four convolution launches.
 FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
-# ... and the same for their backward-data chain, as a bit mask over the stacks.  Default: the 11x11 stack only.  The
-# 21x21 chain measures neutral to slightly slower fused (1.473 ms per 256-sample step with mask 4, 1.479 with 2,
-# 1.493 with 6, 1.485 with 0): its one-workgroup-per-CU kernel leaves the weight-gradient stream nothing to overlap
-# with and releases the three gradients those kernels wait for only at its end.
-FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "4"))
+# ... and the same for their backward-data chain, as a bit mask over the stacks (per 256-sample step, same box:
+# 1.476 ms with mask 0, 1.450 with 4 (11x11), 1.404 with 2 (21x21), 1.408 with 6).
+FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "6"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
