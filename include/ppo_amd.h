@@ -378,6 +378,19 @@ int ppo_impala_stack_tail_backward_f32(const float *g, const float *const *packe
                                        float *da1, float *g1, float *da0, float *g0, int n_images, int channels,
                                        int h, int w, void *stream);
 
+/*
+ * A whole stack in one launch, for the stack whose input map fits LDS next to its pre-pool map (32 channels,
+ * 21x21 -> 11x11): first convolution (no ReLU on read) + bias, 3x3 / stride 2 / pad 1 max-pool with argmax
+ * (rl/impala.py:96-99; same tie / padding / NaN rule as ppo_maxpool3x3s2_forward_f32), then the two residual blocks as
+ * ppo_impala_stack_tail_forward_f32.  packed_weights / biases: HOST arrays of 5 device pointers (firstconv,
+ * block0.conv0, block0.conv1, block1.conv0, block1.conv1).  pooled [n,C,HO,WO], argmax (uint8) and a0, q0, a1 are
+ * nullable (inference writes only q1).  Bit-identical to ppo_conv3x3_pool_forward_packed_f32 followed by the tail.
+ */
+int ppo_impala_stack_full_supported(int channels, int h, int w);
+int ppo_impala_stack_full_forward_f32(const float *in, const float *const *packed_weights, const float *const *biases,
+                                      float *pooled, uint8_t *argmax, float *a0, float *q0, float *a1, float *q1,
+                                      int n_images, int channels, int h, int w, void *stream);
+
 /* ------------------------------------------------------------------------
  * Observation normalisation (`--observation_normalization`, rl/models.py:661-694): running per-feature
  * mean / variance (utils.RunningMeanStd, rl/utils.py:379-455) kept on the device in float64, and the

@@ -18,6 +18,8 @@
 // Each convolution is the implicit GEMM of conv3x3.hip (same flat band layout with TR = H, same K order, same
 // epilogue arithmetic: results are bit-identical to the four separate launches); its weights are the pre-packed A
 // operand (ppo_conv3x3_pack_weights_f32), re-loaded into registers at each layer switch.
+#include <type_traits>
+
 #include "common.h"
 #include "conv_stage.h"
 #include "mfma.h"
@@ -240,6 +242,259 @@ int launch_stack_tail(const StackTailArgs &args, hipStream_t st)
     return check_launch("stack_tail_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// A whole stack in one launch: first convolution + 3x3/s2 max-pool + the two residual blocks, for the stack whose
+// input map fits LDS next to its pre-pool map (32 channels at 21x21 -> 11x11: 2 x 63.5 KB).
+//   c = conv(in) + b   (no ReLU on read: rl/impala.py:96-97 feeds the previous stack's output as is)
+//   p = maxpool3x3s2(c), idx = argmax tap (ties to the first tap in row-major order, padding excluded, NaN propagates:
+//       the rule of conv3x3_pool_kernel / maxpool_fwd_kernel / F.max_pool2d)
+//   then the residual blocks on p exactly as stack_tail_kernel (the small maps reuse the input map's LDS).
+// resident_conv is the layer body of stack_tail_kernel as a function (that kernel keeps its own copy: it is tuned
+// and measured as it stands).
+// Compile-time loop: f(integral_constant<I>) for I in [I, N).  (With two convolution geometries in one kernel a
+// `#pragma unroll` K loop exceeds the unroller's budget and stays a real loop, with the weights in scratch.)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct LaneMap {  // where this lane's pixel tiles live in a resident map
+    template <int MT>
+    struct T {
+        int pix[MT], lofs[MT];
+        float hi_l[MT], hi_r[MT];
+    };
+};
+
+template <int H, int W, int PLANE, int G, int MT>
+__device__ __forceinline__ void lane_map_init(LaneMap::T<MT> &lm, int pixel_wave, int l15, int g)
+{
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = (pixel_wave * MT + m) * 16 + l15;
+        lm.pix[m] = p;
+        const int pc = p < H * W ? p : 0;
+        lm.lofs[m] = G + pc - 1 + g * PLANE;
+        lm.hi_l[m] = (pc % W == 0) ? 0.f : INFINITY;
+        lm.hi_r[m] = (pc % W == W - 1) ? 0.f : INFINITY;
+    }
+}
+
+// dst = conv(f(src)) + bias (+ dst's previous value when `residual`), f = ReLU (RELU_IN) or identity; both maps in LDS at
+// smem + src_off / dst_off; `save` (nullable) receives the HBM copy of this image's result.
+template <int C, int H, int W, int MT, int NTOT, int NT, bool RELU_IN>
+__device__ __forceinline__ void resident_conv(float *smem, int src_off, int dst_off, bool residual, const float *wpk,
+                                              const float *bias, float *save, const LaneMap::T<MT> &lm, int n0, int lane)
+{
+    constexpr int ROWS = H + 2, G = 4, PLANE_RAW = ROWS * W + 2 * G;
+    constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;
+    constexpr int KS = 9 * (C / 4);
+    const int g = lane >> 4;
+    float wa[NT][KS];
+    const float4 *pw = reinterpret_cast<const float4 *>(wpk);
+#pragma unroll
+    for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float4 v = pw[(s4 * NTOT + n0 + n) * 64 + lane];
+            wa[n][4 * s4 + 0] = v.x;
+            wa[n][4 * s4 + 1] = v.y;
+            wa[n][4 * s4 + 2] = v.z;
+            wa[n][4 * s4 + 3] = v.w;
+        }
+    float bias_r[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[n][r] = bias[(n0 + n) * 16 + g * 4 + r];
+
+    __syncthreads();  // the source map is complete
+    int base[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) base[m] = lm.lofs[m] + src_off;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int SB = (MT * NT >= 4) ? 2 : 4;
+    constexpr int NB = (KS + SB - 1) / SB;
+    float raw[2][SB][MT];
+    auto load_block = [&](int j, float (&r)[SB][MT]) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int s = j * SB + u;
+            if (s < KS) {
+                const int tap = s / (C / 4), cs = s % (C / 4);
+                const int tap_off = (tap / 3) * W + (tap % 3);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) r[u][m] = smem[base[m] + cs * 4 * PLANE + tap_off];
+            }
+        }
+    };
+    load_block(0, raw[0]);
+    static_for<0, NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        float bv[SB][MT];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int s = j * SB + u;
+            if (s < KS) {
+                const int kx = (s / (C / 4)) % 3;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float x = raw[j & 1][u][m];
+                    if (kx != 1) {
+                        const float hi = kx == 0 ? lm.hi_l[m] : lm.hi_r[m];
+                        x = __builtin_amdgcn_fmed3f(x, RELU_IN ? 0.f : -hi, hi);
+                    } else if (RELU_IN) {
+                        x = relu1(x);
+                    }
+                    bv[u][m] = x;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j + 1 < NB) load_block(j + 1, raw[(j + 1) & 1]);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int s = j * SB + u;
+            if (s < KS) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[n][m] = mfma16(wa[n][s], bv[u][m], acc[n][m]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (lm.pix[m] < H * W) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (n0 + n) * 16 + g * 4 + r;
+                    const int lo = dst_off + co * PLANE + G + W + lm.pix[m];
+                    float val = acc[n][m][r] + bias_r[n][r];
+                    if (residual) val = val + smem[lo];
+                    smem[lo] = val;
+                    if (save) save[(size_t)co * (H * W) + lm.pix[m]] = val;
+                }
+        }
+    }
+}
+
+struct StackFullArgs {
+    const float *in;       // [n, C, HI, WI] the previous stack's output
+    const float *w[5];     // packed forward weights: firstconv, block0.conv0, block0.conv1, block1.conv0, block1.conv1
+    const float *bias[5];
+    float *pooled;         // [n, C, HO, WO] p (nullable: inference)
+    uint8_t *argmax;       // [n, C, HO, WO] winning tap 0..8 (nullable)
+    float *save[4];        // a0, q0, a1, q1 on [n, C, HO, WO]; q1 required
+    int n_images;
+};
+
+template <int C, int HI, int WI, int MTI, int HO, int WO, int MTO, int NW, int NSPLIT>
+__global__ __launch_bounds__(NW * NSPLIT * 64) void stack_full_kernel(StackFullArgs a)
+{
+    using SI = StackCfg<C, HI, WI, MTI, NW, NSPLIT>;
+    using SO = StackCfg<C, HO, WO, MTO, NW, NSPLIT>;
+    static_assert(HO == (HI + 1) / 2 && WO == (WI + 1) / 2, "3x3 / stride 2 / pad 1 pooling");
+    static_assert(2 * SO::LDS_MAP <= SI::LDS_MAP, "the small maps reuse the input map's LDS");
+    constexpr int NT = SI::NTL, WAVES = SI::WAVES, THREADS = WAVES * 64;
+    constexpr int A_OFF = 0, B_OFF = SI::LDS_MAP, X_OFF = 0, Y_OFF = SO::LDS_MAP;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = tid >> 6, pixel_wave = wave % NW, n0 = (wave / NW) * NT;
+
+    LaneMap::T<MTI> lmi;
+    LaneMap::T<MTO> lmo;
+    lane_map_init<HI, WI, SI::PLANE, SI::G, MTI>(lmi, pixel_wave, l15, g);
+    lane_map_init<HO, WO, SO::PLANE, SO::G, MTO>(lmo, pixel_wave, l15, g);
+
+    for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
+        __syncthreads();  // the previous image's last readers of the small maps are done
+        zero_lds<SI::LDS_MAP, THREADS>(smem + A_OFF, tid);  // guards of the input map (its halo rows: the stage below)
+        __syncthreads();
+        stage_band_chunk_dma<C, HI, WI, SI::ROWS, SI::PLANE, SI::G, WAVES>(a.in, img, 0, smem + A_OFF, tid);
+        // ---- first convolution: A -> B (no ReLU on read, no residual, not saved: only its pooled form leaves the CU)
+        resident_conv<C, HI, WI, MTI, SI::NT, NT, false>(smem, A_OFF, B_OFF, false, a.w[0], a.bias[0], nullptr, lmi, n0, lane);
+        __syncthreads();  // B is complete and nobody reads A any more
+        zero_lds<2 * SO::LDS_MAP, THREADS>(smem + X_OFF, tid);  // X and Y (inside A's region): halo rows and guards
+        __syncthreads();
+        // ---- pool B -> X (+ HBM copy and argmax); a wave pass covers RPW pooled rows of WO outputs
+        {
+            constexpr int RPW = 64 / WO;
+            const int sub = lane / WO, xo = lane % WO;
+            const size_t out_img = (size_t)img * C * HO * WO;
+            for (int u0 = wave * RPW; u0 < C * HO; u0 += WAVES * RPW) {
+                const int u = u0 + sub;
+                const int co = u / HO, yo = u % HO;
+                if (sub < RPW && co < C) {
+                    const float *src = smem + B_OFF + co * SI::PLANE + SI::G + WI + (2 * yo - 1) * WI + 2 * xo - 1;
+                    float best = -INFINITY;
+                    int best_tap = 0;
+                    bool found = false;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const bool row_ok = (ky == 0) ? yo > 0 : (ky == 1 ? true : 2 * yo + 1 < HI);
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const bool col_ok = (kx == 0) ? xo > 0 : (kx == 1 ? true : 2 * xo + 1 < WI);
+                            if (row_ok && col_ok) {
+                                const float v = src[ky * WI + kx];
+                                if (!found || v > best || v != v) {
+                                    best = v;
+                                    best_tap = ky * 3 + kx;
+                                    found = true;
+                                }
+                            }
+                        }
+                    }
+                    smem[X_OFF + co * SO::PLANE + SO::G + WO + yo * WO + xo] = best;
+                    const size_t oi = out_img + ((size_t)co * HO + yo) * WO + xo;
+                    if (a.pooled) a.pooled[oi] = best;
+                    if (a.argmax) a.argmax[oi] = (uint8_t)best_tap;
+                }
+            }
+        }
+        // ---- the residual blocks on the pooled map (each layer starts with the barrier that publishes its source)
+        const size_t out_img = (size_t)img * C * HO * WO;
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            const int odd = layer & 1;
+            float *save = a.save[layer] ? a.save[layer] + out_img : nullptr;
+            resident_conv<C, HO, WO, MTO, SO::NT, NT, true>(smem, odd ? Y_OFF : X_OFF, odd ? X_OFF : Y_OFF, odd != 0,
+                                                            a.w[1 + layer], a.bias[1 + layer], save, lmo, n0, lane);
+        }
+    }
+}
+
+template <int C, int HI, int WI, int MTI, int HO, int WO, int MTO, int NW, int NSPLIT>
+int launch_stack_full(const StackFullArgs &args, hipStream_t st)
+{
+    using SI = StackCfg<C, HI, WI, MTI, NW, NSPLIT>;
+    constexpr size_t kLds = 2 * (size_t)SI::LDS_MAP * 4;
+    auto kern = stack_full_kernel<C, HI, WI, MTI, HO, WO, MTO, NW, NSPLIT>;
+    static bool ready = false;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kLds);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_full: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        ready = true;
+    }
+    const int grid = args.n_images < 256 ? args.n_images : 256;  // one workgroup per CU (LDS)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SI::WAVES * 64), kLds, st, args);
+    return check_launch("stack_full_kernel");
+}
+
 }  // namespace
 }  // namespace ppo
 
@@ -309,4 +564,38 @@ extern "C" int ppo_impala_stack_tail_backward_f32(const float *g, const float *c
     if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, true>(args, st);
     if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, true>(args, st);
     return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+}
+
+extern "C" int ppo_impala_stack_full_supported(int channels, int h, int w) { return channels == 32 && h == 21 && w == 21; }
+
+extern "C" int ppo_impala_stack_full_forward_f32(const float *in, const float *const *packed_weights,
+                                                 const float *const *biases, float *pooled, uint8_t *argmax, float *a0,
+                                                 float *q0, float *a1, float *q1, int n_images, int channels, int h, int w,
+                                                 void *stream)
+{
+    using namespace ppo;
+    if (n_images < 0) return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: negative batch");
+    if (n_images == 0) return PPO_OK;
+    if (!in || !packed_weights || !biases || !q1)
+        return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: null pointer");
+    StackFullArgs args;
+    args.in = in;
+    for (int l = 0; l < 5; ++l) {
+        if (!packed_weights[l] || !biases[l])
+            return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: null weights / bias of layer %d", l);
+        if (!aligned(packed_weights[l], 16))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_full_forward_f32: packed weights must be 16-byte aligned");
+        args.w[l] = packed_weights[l];
+        args.bias[l] = biases[l];
+    }
+    args.pooled = pooled;
+    args.argmax = argmax;
+    args.save[0] = a0;
+    args.save[1] = q0;
+    args.save[2] = a1;
+    args.save[3] = q1;
+    args.n_images = n_images;
+    if (channels == 32 && h == 21 && w == 21)
+        return launch_stack_full<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
+    return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }

@@ -37,6 +37,9 @@ PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
 # The two residual blocks of a stack as one launch with the image resident in LDS (csrc/stack_fused.hip), where the
 # geometry has a kernel (32 channels at 11x11) and the packed weights exist; 0 = four convolution launches.
 FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
+# A whole stack (first convolution + max-pool + both blocks) in one launch where its input map and pre-pool map fit LDS
+# together (32 channels at 21x21 -> 11x11, i.e. the last stack of the 84x84 net); 0 = conv+pool launch, then the tail.
+FUSE_STACK_FULL = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL", "1"))
 # ... and the same for their backward-data chain, as a bit mask over the stacks (per 256-sample step, same box:
 # 1.476 ms with mask 0, 1.450 with 4 (11x11), 1.404 with 2 (21x21), 1.408 with 6).
 FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "6"))
@@ -523,6 +526,24 @@ class DualHeadNet:
         self._linear(a1, sp.hidden_units, "encoder.fc2", h, tag=tag)
         return {"x": x, "a1": a1, "h": h}
 
+    def _stack_full_ptrs(self, si, cin, cout, h, w):
+        """Host arrays of the five packed-weight / bias pointers (firstconv + the four block convolutions) of stack
+        si for the whole-stack kernel, or None when it does not apply."""
+        if not (FUSE_STACK_FULL and FUSE_STACK_TAIL) or self.spec.n_block != 2 or cin != cout \
+                or not self.lib.ppo_impala_stack_full_supported(cout, h, w):
+            return None
+        cached = self._tail_ptrs.get(("full", si))
+        if cached is None:
+            names = [f"encoder.stacks.{si}.firstconv"] + [f"encoder.stacks.{si}.blocks.{bi}.conv{ci}"
+                                                          for bi in range(2) for ci in range(2)]
+            pks = [self._pk.get((n, 0)) for n in names]
+            if any(pk is None for pk in pks):
+                return None
+            cached = ((ctypes.c_void_p * 5)(*[pk.data_ptr() for pk in pks]),
+                      (ctypes.c_void_p * 5)(*[self.params[n + ".bias"].data_ptr() for n in names]))
+            self._tail_ptrs[("full", si)] = cached
+        return cached
+
     def _stack_tail_ptrs(self, si, cout, ho, wo):
         """Host arrays of the four packed-weight / bias pointers of stack si's residual blocks for the fused
         kernel, or None when it does not apply.  The arrays are cached: packed buffers and parameter views keep
@@ -549,6 +570,17 @@ class DualHeadNet:
             p = self._buf(f"{tag}p{si}", (B, cout, ho, wo))
             idx = self._buf(f"{tag}idx{si}", (B, cout, ho, wo), torch.uint8) if train else None
             wname = f"encoder.stacks.{si}.firstconv"
+            full = self._stack_full_ptrs(si, cin, cout, h, w) if cur_mode == IN_NONE else None
+            if full is not None:
+                names = [f"{tag}a{si}_0", f"{tag}q{si}_0", f"{tag}a{si}_1", f"{tag}q{si}_1"]
+                a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
+                self._call("ppo_impala_stack_full_forward_f32", _p(cur), full[0], full[1], _p(p) if train else None,
+                           _p(idx), _p(a0) if train else None, _p(q0) if train else None, _p(a1) if train else None,
+                           _p(q1), B, cout, h, w)
+                acts[f"in{si}"], acts[f"idx{si}"] = cur, idx
+                acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"] = p, a0, q0, a1
+                cur, cur_mode = q1, IN_NONE
+                continue
             if FUSE_POOL_STACKS >> si & 1:
                 # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
                 pk = self._pk.get((wname, 0))

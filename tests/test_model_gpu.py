@@ -172,6 +172,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
     torch.manual_seed(3)
     dims, nA = (4, 84, 84), 6
     monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
+    monkeypatch.setattr(models, "FUSE_STACK_FULL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_TAIL_BWD", 6)  # both backward instances, whatever the default mask
     a = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     assert a.lib.ppo_impala_stack_tail_supported(32, 11, 11) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 21, 21) == 1
@@ -184,7 +185,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
         for _ in range(2):  # the second pass replays the recorded launch plan
             monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
             ha = a.forward(x)["_heads"].clone()
-            assert {1, 2} <= set(a._tail_ptrs), "the fused path did not engage for both 32-channel stacks"
+            assert {1, ("full", 2)} <= set(a._tail_ptrs), "the fused paths did not engage (tail of stack 1, whole stack 2)"
             monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
             hb = b.forward(x)["_heads"].clone()
             assert not b._tail_ptrs
@@ -195,7 +196,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
         adv, ret = torch.randn(B, device="cuda", generator=g), torch.randn(B, 1, device="cuda", generator=g)
         monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
         acts_a = a.encode(x, train=True)
-        saved = {k: acts_a[k].clone() for k in ("q1_0_in", "a1_0", "q1_1_in", "a1_1", "in2",
+        saved = {k: acts_a[k].clone() for k in ("q1_0_in", "a1_0", "q1_1_in", "a1_1", "in2", "idx2",
                                                 "q2_0_in", "a2_0", "q2_1_in", "a2_1", "flat")}
         a.ppo_minibatch(x, actions, pac, logp, adv, ret)
         monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
