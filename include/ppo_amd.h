@@ -386,7 +386,17 @@ int ppo_impala_stack_tail_backward_f32(const float *g, const float *const *packe
  * block0.conv0, block0.conv1, block1.conv0, block1.conv1).  pooled [n,C,HO,WO], argmax (uint8) and a0, q0, a1 are
  * nullable (inference writes only q1).  Bit-identical to ppo_conv3x3_pool_forward_packed_f32 followed by the tail.
  */
+/*
+ * ppo_impala_stack_full_backward_f32: backward-data of that stack in one launch.  g = d loss / d q1 [n,C,HO,WO];
+ * packed_weights_t: HOST array of 5 backward-data packed weights (block1.conv1, block1.conv0, block0.conv1,
+ * block0.conv0, firstconv); masks: HOST array of 4 forward maps (a1, q0, a0, p).  Writes da1, g1, da0, g0 (as
+ * ppo_impala_stack_tail_backward_f32), dc = ppo_maxpool3x3s2_backward_f32(g0, argmax) [n,C,h,w] and
+ * g_prev = ppo_conv3x3_backward_data_packed_f32(dc, firstconv) [n,C,h,w], all bit-identical to those launches.
+ */
 int ppo_impala_stack_full_supported(int channels, int h, int w);
+int ppo_impala_stack_full_backward_f32(const float *g, const float *const *packed_weights_t, const float *const *masks,
+                                       const uint8_t *argmax, float *da1, float *g1, float *da0, float *g0, float *dc,
+                                       float *g_prev, int n_images, int channels, int h, int w, void *stream);
 int ppo_impala_stack_full_forward_f32(const float *in, const float *const *packed_weights, const float *const *biases,
                                       float *pooled, uint8_t *argmax, float *a0, float *q0, float *a1, float *q1,
                                       int n_images, int channels, int h, int w, void *stream);

@@ -286,9 +286,12 @@ __device__ __forceinline__ void lane_map_init(LaneMap::T<MT> &lm, int pixel_wave
 
 // dst = conv(f(src)) + bias (+ dst's previous value when `residual`), f = ReLU (RELU_IN) or identity; both maps in LDS at
 // smem + src_off / dst_off; `save` (nullable) receives the HBM copy of this image's result.
-template <int C, int H, int W, int MT, int NTOT, int NT, bool RELU_IN>
+// GATED (backward-data): the result is zeroed where `mask` (this image's forward pre-activation map) is <= 0, before
+// the residual add; bias is then null.
+template <int C, int H, int W, int MT, int NTOT, int NT, bool RELU_IN, bool GATED = false>
 __device__ __forceinline__ void resident_conv(float *smem, int src_off, int dst_off, bool residual, const float *wpk,
-                                              const float *bias, float *save, const LaneMap::T<MT> &lm, int n0, int lane)
+                                              const float *bias, float *save, const LaneMap::T<MT> &lm, int n0, int lane,
+                                              const float *mask = nullptr)
 {
     constexpr int ROWS = H + 2, G = 4, PLANE_RAW = ROWS * W + 2 * G;
     constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;
@@ -310,7 +313,17 @@ __device__ __forceinline__ void resident_conv(float *smem, int src_off, int dst_
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias_r[n][r] = bias[(n0 + n) * 16 + g * 4 + r];
+        for (int r = 0; r < 4; ++r) bias_r[n][r] = (GATED || !bias) ? 0.f : bias[(n0 + n) * 16 + g * 4 + r];
+    float gate[GATED ? MT : 1][NT][4];
+    if constexpr (GATED) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    gate[m][n][r] = lm.pix[m] < H * W ? mask[((n0 + n) * 16 + g * 4 + r) * (H * W) + lm.pix[m]] : 1.f;
+    }
 
     __syncthreads();  // the source map is complete
     int base[MT];
@@ -383,6 +396,7 @@ __device__ __forceinline__ void resident_conv(float *smem, int src_off, int dst_
                     const int co = (n0 + n) * 16 + g * 4 + r;
                     const int lo = dst_off + co * PLANE + G + W + lm.pix[m];
                     float val = acc[n][m][r] + bias_r[n][r];
+                    if constexpr (GATED) val = gate[m][n][r] > 0.f ? val : 0.f;
                     if (residual) val = val + smem[lo];
                     smem[lo] = val;
                     if (save) save[(size_t)co * (H * W) + lm.pix[m]] = val;
@@ -475,6 +489,109 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_full_kernel(StackFullA
                                                             a.w[1 + layer], a.bias[1 + layer], save, lmo, n0, lane);
         }
     }
+}
+
+// Backward-data of the same stack in one launch: the blocks' gated transposed chain on the pooled map (as
+// stack_tail_kernel<.., BACKWARD>), max-pool backward into the pre-pool gradient dc, and the first convolution's
+// transposed pass, which yields the gradient of the previous stack's output:
+//   da1, g1, da0, g0 as ppo_impala_stack_tail_backward_f32;  dc = maxpool_bwd(g0, argmax)  (summation order of
+//   maxpool_bwd_kernel: windows (oy0, k), (oy0, k + 1), (oy0 + 1, k), (oy0 + 1, k + 1));  g_prev = conv_first^T(dc).
+// All of them go to HBM as well: the weight-gradient kernels read them.
+struct StackFullBwdArgs {
+    const float *g;         // [n, C, HO, WO] d loss / d (stack output)
+    const float *w[5];      // backward-data packed weights: block1.conv1, block1.conv0, block0.conv1, block0.conv0, firstconv
+    const float *mask[4];   // a1, q0, a0, p  ([n, C, HO, WO])
+    const uint8_t *argmax;  // [n, C, HO, WO]
+    float *save[4];         // da1, g1, da0, g0
+    float *dc;              // [n, C, HI, WI]
+    float *g_prev;          // [n, C, HI, WI]
+    int n_images;
+};
+
+template <int C, int HI, int WI, int MTI, int HO, int WO, int MTO, int NW, int NSPLIT>
+__global__ __launch_bounds__(NW * NSPLIT * 64) void stack_full_bwd_kernel(StackFullBwdArgs a)
+{
+    using SI = StackCfg<C, HI, WI, MTI, NW, NSPLIT>;
+    using SO = StackCfg<C, HO, WO, MTO, NW, NSPLIT>;
+    static_assert(2 * SO::LDS_MAP <= SI::LDS_MAP, "the small maps live inside the first big map's LDS");
+    constexpr int NT = SI::NTL, WAVES = SI::WAVES, THREADS = WAVES * 64;
+    constexpr int A_OFF = 0, B_OFF = SI::LDS_MAP, X_OFF = 0, Y_OFF = SO::LDS_MAP;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = tid >> 6, pixel_wave = wave % NW, n0 = (wave / NW) * NT;
+
+    LaneMap::T<MTI> lmi;
+    LaneMap::T<MTO> lmo;
+    lane_map_init<HI, WI, SI::PLANE, SI::G, MTI>(lmi, pixel_wave, l15, g);
+    lane_map_init<HO, WO, SO::PLANE, SO::G, MTO>(lmo, pixel_wave, l15, g);
+
+    zero_lds<SI::LDS_MAP, THREADS>(smem + B_OFF, tid);  // dc's halo rows and guards: only its interior is ever written
+
+    for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
+        __syncthreads();  // the previous image's transposed first convolution has read B and written A
+        zero_lds<2 * SO::LDS_MAP, THREADS>(smem + X_OFF, tid);  // X, Y: halo rows and guards (A's interior overlaps them)
+        __syncthreads();
+        stage_band_chunk_dma<C, HO, WO, SO::ROWS, SO::PLANE, SO::G, WAVES>(a.g, img, 0, smem + X_OFF, tid);
+        const size_t small_img = (size_t)img * C * HO * WO, big_img = (size_t)img * C * HI * WI;
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            const int odd = layer & 1;
+            resident_conv<C, HO, WO, MTO, SO::NT, NT, false, true>(smem, odd ? Y_OFF : X_OFF, odd ? X_OFF : Y_OFF, odd != 0,
+                                                                   a.w[layer], nullptr, a.save[layer] + small_img, lmo, n0,
+                                                                   lane, a.mask[layer] + small_img);
+        }
+        __syncthreads();  // g0 is complete in X
+        // ---- max-pool backward: gather per pre-pool pixel, X (g0) + argmax -> B (dc) and HBM
+        {
+            const uint8_t *am = a.argmax + small_img;
+            for (int e = tid; e < C * HI * WI; e += THREADS) {
+                const int co = e / (HI * WI), r = e % (HI * WI);
+                const int iy = r / WI, ix = r % WI;
+                const int k = ix >> 1, oy0 = iy >> 1;
+                const int ky0 = (iy & 1) ? 2 : 1;
+                const bool has_oy1 = (iy & 1) && (oy0 + 1 < HO);
+                const bool odd_x = ix & 1;
+                const bool has_ox1 = odd_x && (k + 1 < WO);
+                const int kx0 = odd_x ? 2 : 1;  // this pixel's tap column inside window ox = k
+                const float *gx = smem + X_OFF + co * SO::PLANE + SO::G + WO;
+                const uint8_t *ac = am + co * (HO * WO);
+                float sum = 0.f;
+                {
+                    const int i00 = oy0 * WO + k;
+                    if (ac[i00] == ky0 * 3 + kx0) sum += gx[i00];
+                    if (has_ox1 && ac[i00 + 1] == ky0 * 3 + 0) sum += gx[i00 + 1];
+                }
+                if (has_oy1) {
+                    const int i10 = (oy0 + 1) * WO + k;
+                    if (ac[i10] == kx0) sum += gx[i10];
+                    if (has_ox1 && ac[i10 + 1] == 0) sum += gx[i10 + 1];
+                }
+                smem[B_OFF + co * SI::PLANE + SI::G + WI + r] = sum;
+                a.dc[big_img + e] = sum;
+            }
+        }
+        // ---- first convolution, transposed: B (dc) -> A (overwrites the small maps; its barrier publishes B)
+        resident_conv<C, HI, WI, MTI, SI::NT, NT, false, false>(smem, B_OFF, A_OFF, false, a.w[4], nullptr,
+                                                                a.g_prev + big_img, lmi, n0, lane);
+    }
+}
+
+template <int C, int HI, int WI, int MTI, int HO, int WO, int MTO, int NW, int NSPLIT>
+int launch_stack_full_bwd(const StackFullBwdArgs &args, hipStream_t st)
+{
+    using SI = StackCfg<C, HI, WI, MTI, NW, NSPLIT>;
+    constexpr size_t kLds = 2 * (size_t)SI::LDS_MAP * 4;
+    auto kern = stack_full_bwd_kernel<C, HI, WI, MTI, HO, WO, MTO, NW, NSPLIT>;
+    static bool ready = false;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kLds);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_full_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        ready = true;
+    }
+    const int grid = args.n_images < 256 ? args.n_images : 256;  // one workgroup per CU (LDS)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SI::WAVES * 64), kLds, st, args);
+    return check_launch("stack_full_bwd_kernel");
 }
 
 template <int C, int HI, int WI, int MTI, int HO, int WO, int MTO, int NW, int NSPLIT>
@@ -598,4 +715,37 @@ extern "C" int ppo_impala_stack_full_forward_f32(const float *in, const float *c
     if (channels == 32 && h == 21 && w == 21)
         return launch_stack_full<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
     return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+}
+
+extern "C" int ppo_impala_stack_full_backward_f32(const float *g, const float *const *packed_weights_t,
+                                                  const float *const *masks, const uint8_t *argmax, float *da1, float *g1,
+                                                  float *da0, float *g0, float *dc, float *g_prev, int n_images,
+                                                  int channels, int h, int w, void *stream)
+{
+    using namespace ppo;
+    if (n_images < 0) return fail(PPO_E_INVALID, "ppo_impala_stack_full_backward_f32: negative batch");
+    if (n_images == 0) return PPO_OK;
+    if (!g || !packed_weights_t || !masks || !argmax || !da1 || !g1 || !da0 || !g0 || !dc || !g_prev)
+        return fail(PPO_E_INVALID, "ppo_impala_stack_full_backward_f32: null pointer");
+    StackFullBwdArgs args;
+    args.g = g;
+    for (int l = 0; l < 5; ++l) {
+        if (!packed_weights_t[l] || (l < 4 && !masks[l]))
+            return fail(PPO_E_INVALID, "ppo_impala_stack_full_backward_f32: null weights / mask of layer %d", l);
+        if (!aligned(packed_weights_t[l], 16))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_full_backward_f32: packed weights must be 16-byte aligned");
+        args.w[l] = packed_weights_t[l];
+        if (l < 4) args.mask[l] = masks[l];
+    }
+    args.argmax = argmax;
+    args.save[0] = da1;
+    args.save[1] = g1;
+    args.save[2] = da0;
+    args.save[3] = g0;
+    args.dc = dc;
+    args.g_prev = g_prev;
+    args.n_images = n_images;
+    if (channels == 32 && h == 21 && w == 21)
+        return launch_stack_full_bwd<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
+    return fail(PPO_E_INVALID, "ppo_impala_stack_full_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }

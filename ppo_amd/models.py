@@ -40,6 +40,11 @@ FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
 # A whole stack (first convolution + max-pool + both blocks) in one launch where its input map and pre-pool map fit LDS
 # together (32 channels at 21x21 -> 11x11, i.e. the last stack of the 84x84 net); 0 = conv+pool launch, then the tail.
 FUSE_STACK_FULL = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL", "1"))
+# ... and its backward-data pass (blocks + max-pool backward + transposed first convolution) likewise.  Off by default:
+# bit-identical, but 1.445 ms per 256-sample step against 1.395 without it — it holds a whole CU's LDS, so the
+# weight-gradient kernels on the side stream get nothing to overlap with for its duration, and releases the five
+# gradients they wait for only at its end.
+FUSE_STACK_FULL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL_BWD", "0"))
 # ... and the same for their backward-data chain, as a bit mask over the stacks (per 256-sample step, same box:
 # 1.476 ms with mask 0, 1.450 with 4 (11x11), 1.404 with 2 (21x21), 1.408 with 6).
 FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "6"))
@@ -771,6 +776,25 @@ class DualHeadNet:
 
         for si in reversed(range(len(sp.stacks))):
             cin, cout, hh, ww, ho, wo = sp.stacks[si]
+            full_w = self._stack_full_bwd_ptrs(si, cin, cout, hh, ww) if si > 0 else None
+            if full_w is not None:
+                # blocks + max-pool backward + transposed first convolution of the stack in one launch
+                b0, b1 = f"encoder.stacks.{si}.blocks.0", f"encoder.stacks.{si}.blocks.1"
+                p_in, a0, q0, a1 = acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"]
+                da1, g1, da0, g0 = (self._buf(nm, (B, cout, ho, wo)) for nm in
+                                    (f"g{si}_1_da", f"g{si}_1_in", f"g{si}_0_da", f"g{si}_0_in"))
+                dc = self._buf(f"g{si}_dc", (B, cout, hh, ww))
+                g_prev = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
+                wgrad(a1, IN_RELU, g, b1 + ".conv1", B, cout, cout, ho, wo)
+                masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p_in.data_ptr())
+                self._call("ppo_impala_stack_full_backward_f32", _p(g), full_w, masks, _p(acts[f"idx{si}"]), _p(da1), _p(g1),
+                           _p(da0), _p(g0), _p(dc), _p(g_prev), B, cout, hh, ww)
+                wgrad(q0, IN_RELU, da1, b1 + ".conv0", B, cout, cout, ho, wo)
+                wgrad(a0, IN_RELU, g1, b0 + ".conv1", B, cout, cout, ho, wo)
+                wgrad(p_in, IN_RELU, da0, b0 + ".conv0", B, cout, cout, ho, wo)
+                wgrad(acts[f"in{si}"], IN_NONE, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
+                g = g_prev
+                continue
             tail_w = self._stack_tail_bwd_ptrs(si, cout, ho, wo)
             if tail_w is not None:
                 # the four backward-data convolutions of the stack's blocks in one launch (csrc/stack_fused.hip)
@@ -819,6 +843,23 @@ class DualHeadNet:
                     self._call("ppo_conv3x3_wgrad_reduce_f32", ctypes.addressof(table), len(jobs))
         if side is not None:
             main.wait_stream(side)  # all weight gradients are in self.grad before anything reads it
+
+    def _stack_full_bwd_ptrs(self, si, cin, cout, h, w):
+        """Host array of the five backward-data packed weights of stack si in processing order (block1.conv1,
+        block1.conv0, block0.conv1, block0.conv0, firstconv), or None when the whole-stack kernel does not apply."""
+        if not (FUSE_STACK_FULL_BWD and FUSE_STACK_TAIL) or self.spec.n_block != 2 or cin != cout \
+                or not self.lib.ppo_impala_stack_full_supported(cout, h, w):
+            return None
+        cached = self._tail_ptrs.get(("full_bwd", si))
+        if cached is None:
+            names = [f"encoder.stacks.{si}.blocks.{bi}.conv{ci}" for bi in (1, 0) for ci in (1, 0)]
+            names.append(f"encoder.stacks.{si}.firstconv")
+            pks = [self._pk.get((n, 1)) for n in names]
+            if any(pk is None for pk in pks):
+                return None
+            cached = (ctypes.c_void_p * 5)(*[pk.data_ptr() for pk in pks])
+            self._tail_ptrs[("full_bwd", si)] = cached
+        return cached
 
     def _stack_tail_bwd_ptrs(self, si, cout, ho, wo):
         """Host array of the four backward-data packed weights of stack si's blocks in processing order

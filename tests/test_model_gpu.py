@@ -173,6 +173,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
     dims, nA = (4, 84, 84), 6
     monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_FULL", 1)
+    monkeypatch.setattr(models, "FUSE_STACK_FULL_BWD", 1)
     monkeypatch.setattr(models, "FUSE_STACK_TAIL_BWD", 6)  # both backward instances, whatever the default mask
     a = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     assert a.lib.ppo_impala_stack_tail_supported(32, 11, 11) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 21, 21) == 1
@@ -206,4 +207,4 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
         b.ppo_minibatch(x, actions, pac, logp, adv, ret)
         torch.cuda.synchronize()
         assert torch.equal(a.grad, b.grad) and float(a.grad.abs().sum()) > 0, B
-        assert {("bwd", 1), ("bwd", 2)} <= set(a._tail_ptrs), "the fused backward did not engage"
+        assert {("bwd", 1), ("full_bwd", 2)} <= set(a._tail_ptrs), "the fused backward did not engage"
