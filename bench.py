@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_* dense peak (MI355X_MICROARCH.md, Matrix cores)
 PROBE_TRAFFIC_BYTES = int((2 * 11295 + 15009) * 1024)  # conv3x3_kernel<32,32,21,21,IN_RELU> forward, batch 256
+STACK_CHAIN_TRAFFIC_BYTES = int((2 * 8625.0 + 76879.8) * 1024)  # stack_full_kernel chained training forward, batch 256
 STACK_TAIL_TRAFFIC_BYTES = int((2 * 7826.4 + 60447.7) * 1024)  # stack_tail_kernel<32,21,21> training forward, batch 256
 SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write adv4+ret4
 FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
@@ -242,12 +243,15 @@ def main():
     # (stack_tail_kernel<32,21,21>: 4 convolutions, image resident in LDS) or, with PPO_AMD_FUSE_STACK_TAIL=0, the
     # individual conv3x3_kernel<32,32,21,21,IN_RELU> launches.  Only minibatch-sized training launches are timed.
     def probe_match(fn_name, c):
+        if fn_name == "ppo_impala_stack_chain_forward_f32":  # (in, pre_w, pre_b, pre_a0..pre_q1, w, b, pooled, argmax,
+            return c[3] is not None and (c[15], c[16], c[17], c[18]) == (mb, 32, 21, 21)  # a0..q1, n, channels, h, w)
         if fn_name == "ppo_impala_stack_tail_forward_f32":  # (in, w[4], b[4], a0, q0, a1, q1, n, channels, h, w)
             return c[3] is not None and (c[7], c[8], c[9], c[10]) == (mb, 32, 21, 21)
         return c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (mb, 32, 32, 21, 21)
 
     probe = CallProbe(model.policy_net, ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32",
-                                         "ppo_impala_stack_tail_forward_f32"), probe_match)
+                                         "ppo_impala_stack_tail_forward_f32", "ppo_impala_stack_chain_forward_f32"),
+                      probe_match)
     conv_flops = 2 * 9 * 32 * 32 * 21 * 21 * mb
 
     def iteration():
@@ -282,7 +286,19 @@ def main():
     kern_ms = probe.avg_ms()
     fused = probe.seen == "ppo_impala_stack_tail_forward_f32"
     map_bytes = 32 * 21 * 21 * 4 * mb
-    if fused:   # reads the block input, writes a0, q0, a1, q1 for the backward pass
+    small_bytes = 32 * 11 * 11 * 4 * mb
+    if probe.seen == "ppo_impala_stack_chain_forward_f32":
+        # the 21x21 stack's 4 block convolutions, the 11x11 stack's first convolution (on the 21x21 map) + max-pool and
+        # its 4 block convolutions; reads the 21x21 pooled map, writes the 4 + 4 maps the backward pass needs, the
+        # pooled 11x11 map and its uint8 argmax
+        probe_flops = 5 * conv_flops + 4 * (2 * 9 * 32 * 32 * 11 * 11 * mb)
+        probe_bytes = 5 * map_bytes + 5 * small_bytes + small_bytes // 4
+        probe_traffic = STACK_CHAIN_TRAFFIC_BYTES
+        probe_kernel = ("stack_full_kernel<32,21,21 -> 11,11> chained training forward: residual blocks of the 21x21 stack + "
+                        "the whole 11x11 stack (9 convolutions + max-pool) in one launch, maps resident in LDS "
+                        "(ppo_impala_stack_chain_forward_f32, minibatch launches)")
+        probe_source = "profiles/r01l_stack_tail_hbm_traffic.md"
+    elif fused:   # reads the block input, writes a0, q0, a1, q1 for the backward pass
         probe_flops, probe_bytes, probe_traffic = 4 * conv_flops, 5 * map_bytes, STACK_TAIL_TRAFFIC_BYTES
         probe_kernel = ("stack_tail_kernel<32,21,21> training forward: the 4 residual-block convolutions of the 21x21 "
                         "stack in one launch (ppo_impala_stack_tail_forward_f32, minibatch launches)")

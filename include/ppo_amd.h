@@ -394,6 +394,13 @@ int ppo_impala_stack_tail_backward_f32(const float *g, const float *const *packe
  * g_prev = ppo_conv3x3_backward_data_packed_f32(dc, firstconv) [n,C,h,w], all bit-identical to those launches.
  */
 int ppo_impala_stack_full_supported(int channels, int h, int w);
+/* Chained form: the PREVIOUS stack's two residual blocks (on `in` = its pooled map [n,C,h,w]; pre_* as the tail
+ * entry point's arguments, pre_a0 / pre_q0 / pre_a1 / pre_q1 nullable) followed by this whole stack, one launch. */
+int ppo_impala_stack_chain_forward_f32(const float *in, const float *const *pre_packed_weights,
+                                       const float *const *pre_biases, float *pre_a0, float *pre_q0, float *pre_a1,
+                                       float *pre_q1, const float *const *packed_weights, const float *const *biases,
+                                       float *pooled, uint8_t *argmax, float *a0, float *q0, float *a1, float *q1,
+                                       int n_images, int channels, int h, int w, void *stream);
 int ppo_impala_stack_full_backward_f32(const float *g, const float *const *packed_weights_t, const float *const *masks,
                                        const uint8_t *argmax, float *da1, float *g1, float *da0, float *g0, float *dc,
                                        float *g_prev, int n_images, int channels, int h, int w, void *stream);

@@ -412,6 +412,12 @@ struct StackFullArgs {
     float *pooled;         // [n, C, HO, WO] p (nullable: inference)
     uint8_t *argmax;       // [n, C, HO, WO] winning tap 0..8 (nullable)
     float *save[4];        // a0, q0, a1, q1 on [n, C, HO, WO]; q1 required
+    // chained form: `in` is the PREVIOUS stack's pooled map and its two residual blocks run first on the resident
+    // [C, HI, WI] map (as stack_tail_kernel), so that stack's output never leaves LDS on its way into this one
+    const float *pre_w[4];
+    const float *pre_bias[4];
+    float *pre_save[4];    // the previous stack's a0, q0, a1, q1 (nullable: inference)
+    int has_pre;
     int n_images;
 };
 
@@ -433,11 +439,24 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_full_kernel(StackFullA
     lane_map_init<HI, WI, SI::PLANE, SI::G, MTI>(lmi, pixel_wave, l15, g);
     lane_map_init<HO, WO, SO::PLANE, SO::G, MTO>(lmo, pixel_wave, l15, g);
 
+    if (a.has_pre) zero_lds<SI::LDS_MAP, THREADS>(smem + B_OFF, tid);  // halo rows / guards of the blocks' second map
+
     for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
         __syncthreads();  // the previous image's last readers of the small maps are done
         zero_lds<SI::LDS_MAP, THREADS>(smem + A_OFF, tid);  // guards of the input map (its halo rows: the stage below)
         __syncthreads();
         stage_band_chunk_dma<C, HI, WI, SI::ROWS, SI::PLANE, SI::G, WAVES>(a.in, img, 0, smem + A_OFF, tid);
+        if (a.has_pre) {
+            // ---- the previous stack's residual blocks: A <-> B ping-pong, result back in A
+            const size_t big_img = (size_t)img * C * HI * WI;
+#pragma unroll 1
+            for (int layer = 0; layer < 4; ++layer) {
+                const int odd = layer & 1;
+                float *save = a.pre_save[layer] ? a.pre_save[layer] + big_img : nullptr;
+                resident_conv<C, HI, WI, MTI, SI::NT, NT, true>(smem, odd ? B_OFF : A_OFF, odd ? A_OFF : B_OFF, odd != 0,
+                                                                a.pre_w[layer], a.pre_bias[layer], save, lmi, n0, lane);
+            }
+        }
         // ---- first convolution: A -> B (no ReLU on read, no residual, not saved: only its pooled form leaves the CU)
         resident_conv<C, HI, WI, MTI, SI::NT, NT, false>(smem, A_OFF, B_OFF, false, a.w[0], a.bias[0], nullptr, lmi, n0, lane);
         __syncthreads();  // B is complete and nobody reads A any more
@@ -711,10 +730,59 @@ extern "C" int ppo_impala_stack_full_forward_f32(const float *in, const float *c
     args.save[1] = q0;
     args.save[2] = a1;
     args.save[3] = q1;
+    args.has_pre = 0;
+    for (int l = 0; l < 4; ++l) {
+        args.pre_w[l] = nullptr;
+        args.pre_bias[l] = nullptr;
+        args.pre_save[l] = nullptr;
+    }
     args.n_images = n_images;
     if (channels == 32 && h == 21 && w == 21)
         return launch_stack_full<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
     return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+}
+
+extern "C" int ppo_impala_stack_chain_forward_f32(const float *in, const float *const *pre_packed_weights,
+                                                  const float *const *pre_biases, float *pre_a0, float *pre_q0,
+                                                  float *pre_a1, float *pre_q1, const float *const *packed_weights,
+                                                  const float *const *biases, float *pooled, uint8_t *argmax, float *a0,
+                                                  float *q0, float *a1, float *q1, int n_images, int channels, int h, int w,
+                                                  void *stream)
+{
+    using namespace ppo;
+    if (n_images < 0) return fail(PPO_E_INVALID, "ppo_impala_stack_chain_forward_f32: negative batch");
+    if (n_images == 0) return PPO_OK;
+    if (!in || !pre_packed_weights || !pre_biases || !packed_weights || !biases || !q1)
+        return fail(PPO_E_INVALID, "ppo_impala_stack_chain_forward_f32: null pointer");
+    StackFullArgs args;
+    args.in = in;
+    for (int l = 0; l < 5; ++l) {
+        if (!packed_weights[l] || !biases[l] || (l < 4 && (!pre_packed_weights[l] || !pre_biases[l])))
+            return fail(PPO_E_INVALID, "ppo_impala_stack_chain_forward_f32: null weights / bias of layer %d", l);
+        if (!aligned(packed_weights[l], 16) || (l < 4 && !aligned(pre_packed_weights[l], 16)))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_chain_forward_f32: packed weights must be 16-byte aligned");
+        args.w[l] = packed_weights[l];
+        args.bias[l] = biases[l];
+        if (l < 4) {
+            args.pre_w[l] = pre_packed_weights[l];
+            args.pre_bias[l] = pre_biases[l];
+        }
+    }
+    args.pre_save[0] = pre_a0;
+    args.pre_save[1] = pre_q0;
+    args.pre_save[2] = pre_a1;
+    args.pre_save[3] = pre_q1;
+    args.has_pre = 1;
+    args.pooled = pooled;
+    args.argmax = argmax;
+    args.save[0] = a0;
+    args.save[1] = q0;
+    args.save[2] = a1;
+    args.save[3] = q1;
+    args.n_images = n_images;
+    if (channels == 32 && h == 21 && w == 21)
+        return launch_stack_full<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
+    return fail(PPO_E_INVALID, "ppo_impala_stack_chain_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }
 
 extern "C" int ppo_impala_stack_full_backward_f32(const float *g, const float *const *packed_weights_t,

@@ -174,6 +174,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
     monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_FULL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_FULL_BWD", 1)
+    monkeypatch.setattr(models, "FUSE_STACK_CHAIN", 1)
     monkeypatch.setattr(models, "FUSE_STACK_TAIL_BWD", 6)  # both backward instances, whatever the default mask
     a = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     assert a.lib.ppo_impala_stack_tail_supported(32, 11, 11) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 21, 21) == 1
