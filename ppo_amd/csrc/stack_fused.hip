@@ -636,7 +636,8 @@ int launch_stack_full(const StackFullArgs &args, hipStream_t st)
 
 extern "C" int ppo_impala_stack_tail_supported(int channels, int h, int w)
 {
-    return channels == 32 && ((h == 11 && w == 11) || (h == 21 && w == 21));
+    // 84x84 observations: 21x21 and 11x11; 64x64 (procgen): 16x16 and 8x8
+    return channels == 32 && ((h == 11 && w == 11) || (h == 21 && w == 21) || (h == 16 && w == 16) || (h == 8 && w == 8));
 }
 
 extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *const *packed_weights,
@@ -668,6 +669,8 @@ extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *c
     hipStream_t st = as_stream(stream);
     if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, false>(args, st);
     if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, false>(args, st);
+    if (channels == 32 && h == 16 && w == 16) return launch_stack_tail<32, 16, 16, 4, 4, PPO_TAIL_SPLIT, false>(args, st);
+    if (channels == 32 && h == 8 && w == 8) return launch_stack_tail<32, 8, 8, 1, 4, PPO_TAIL_SPLIT, false>(args, st);
     return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }
 
@@ -699,10 +702,15 @@ extern "C" int ppo_impala_stack_tail_backward_f32(const float *g, const float *c
     hipStream_t st = as_stream(stream);
     if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, true>(args, st);
     if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, true>(args, st);
+    if (channels == 32 && h == 16 && w == 16) return launch_stack_tail<32, 16, 16, 4, 4, PPO_TAIL_SPLIT, true>(args, st);
+    if (channels == 32 && h == 8 && w == 8) return launch_stack_tail<32, 8, 8, 1, 4, PPO_TAIL_SPLIT, true>(args, st);
     return fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }
 
-extern "C" int ppo_impala_stack_full_supported(int channels, int h, int w) { return channels == 32 && h == 21 && w == 21; }
+extern "C" int ppo_impala_stack_full_supported(int channels, int h, int w)
+{
+    return channels == 32 && ((h == 21 && w == 21) || (h == 16 && w == 16));
+}
 
 extern "C" int ppo_impala_stack_full_forward_f32(const float *in, const float *const *packed_weights,
                                                  const float *const *biases, float *pooled, uint8_t *argmax, float *a0,
@@ -739,6 +747,8 @@ extern "C" int ppo_impala_stack_full_forward_f32(const float *in, const float *c
     args.n_images = n_images;
     if (channels == 32 && h == 21 && w == 21)
         return launch_stack_full<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
+    if (channels == 32 && h == 16 && w == 16)
+        return launch_stack_full<32, 16, 16, 4, 8, 8, 1, 4, 2>(args, as_stream(stream));
     return fail(PPO_E_INVALID, "ppo_impala_stack_full_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }
 
@@ -782,6 +792,8 @@ extern "C" int ppo_impala_stack_chain_forward_f32(const float *in, const float *
     args.n_images = n_images;
     if (channels == 32 && h == 21 && w == 21)
         return launch_stack_full<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
+    if (channels == 32 && h == 16 && w == 16)
+        return launch_stack_full<32, 16, 16, 4, 8, 8, 1, 4, 2>(args, as_stream(stream));
     return fail(PPO_E_INVALID, "ppo_impala_stack_chain_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }
 
@@ -815,5 +827,7 @@ extern "C" int ppo_impala_stack_full_backward_f32(const float *g, const float *c
     args.n_images = n_images;
     if (channels == 32 && h == 21 && w == 21)
         return launch_stack_full_bwd<32, 21, 21, 7, 11, 11, 2, 4, 2>(args, as_stream(stream));
+    if (channels == 32 && h == 16 && w == 16)
+        return launch_stack_full_bwd<32, 16, 16, 4, 8, 8, 1, 4, 2>(args, as_stream(stream));
     return fail(PPO_E_INVALID, "ppo_impala_stack_full_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
 }

@@ -164,13 +164,13 @@ def test_state_dict_round_trip(gold):
         b.load_state_dict({"nope": torch.zeros(1)})
 
 
-def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
+@pytest.mark.parametrize("dims,nA", [((4, 84, 84), 6), ((3, 64, 64), 15)])
+def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dims, nA):
     """csrc/stack_fused.hip: the two residual blocks of the 11x11 stack in one launch (image resident in LDS) give
     the same bits as the four convolution launches — inference rows, the saved maps of a training forward, and every
     gradient of a PPO minibatch — at ragged batch sizes too."""
     from ppo_amd import models
     torch.manual_seed(3)
-    dims, nA = (4, 84, 84), 6
     monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_FULL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_FULL_BWD", 1)
@@ -178,11 +178,12 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch):
     monkeypatch.setattr(models, "FUSE_STACK_TAIL_BWD", 6)  # both backward instances, whatever the default mask
     a = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     assert a.lib.ppo_impala_stack_tail_supported(32, 11, 11) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 21, 21) == 1
-    assert a.lib.ppo_impala_stack_tail_supported(16, 42, 42) == 0
+    assert a.lib.ppo_impala_stack_tail_supported(16, 42, 42) == 0 and a.lib.ppo_impala_stack_tail_supported(32, 8, 8) == 1
+    assert a.lib.ppo_impala_stack_full_supported(32, 16, 16) == 1 and a.lib.ppo_impala_stack_full_supported(32, 11, 11) == 0
     b = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     b.load_state_dict(a.state_dict())
     g = torch.Generator(device="cuda").manual_seed(5)
-    for B in (1, 37, 256, 300):
+    for B in ((1, 37, 256, 300) if dims[1] == 84 else (5, 256)):
         x = torch.randint(0, 256, (B, *dims), dtype=torch.uint8, device="cuda", generator=g)
         for _ in range(2):  # the second pass replays the recorded launch plan
             monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
