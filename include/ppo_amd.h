@@ -181,6 +181,11 @@ typedef struct ppo_wgrad_job {
 int ppo_conv3x3_backward_weight_slabs_f32(const void *in, int in_mode, const float *dy, void *workspace,
                                           size_t workspace_bytes, int n, int cin, int cout, int h, int w,
                                           int *n_slabs, void *stream);
+/* `count` (1..4) problems of one geometry in one launch: ins / dys / workspaces are HOST arrays of device pointers, each
+ * workspace workspace_bytes long; *n_slabs is the slab count of every one of them.  Same slabs as `count` calls. */
+int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *ins, int in_mode, const float *const *dys,
+                                                void *const *workspaces, size_t workspace_bytes, int count, int n, int cin,
+                                                int cout, int h, int w, int *n_slabs, void *stream);
 int ppo_conv3x3_wgrad_reduce_f32(const ppo_wgrad_job *jobs, int n_jobs, void *stream);
 
 /*

@@ -129,12 +129,23 @@ __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, con
     }
 }
 
+// Up to kWgradBatch independent problems of one geometry per launch (blockIdx.y picks one): the layers of a stack share
+// their geometry and their gradients are all known once its backward-data pass is through, and one launch of 4 x the
+// workgroups has one ramp and one tail where four launches have four (per-launch constant ~10 us).
+constexpr int kWgradBatch = 4;
+struct WgradBatch {
+    const void *in[kWgradBatch];
+    const float *dy[kWgradBatch];
+    float *partial[kWgradBatch];
+};
+
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
-__global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(const void *__restrict__ in_,
-                                                                        const float *__restrict__ dy,
-                                                                        float *__restrict__ partial, int n_images)
+__global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBatch batch, int n_images)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
+    const void *__restrict__ in_ = batch.in[blockIdx.y];
+    const float *__restrict__ dy = batch.dy[blockIdx.y];
+    float *__restrict__ partial = batch.partial[blockIdx.y];
     extern __shared__ __align__(16) float smem[];
     float *s_x = smem;
     float *s_d = smem + C::LDS_X;
@@ -393,7 +404,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_jobs_kernel(ReduceJo
 
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
 int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *workspace, size_t workspace_bytes,
-                 int n_images, int accumulate, hipStream_t st, int *n_slabs_out = nullptr)
+                 int n_images, int accumulate, hipStream_t st, int *n_slabs_out = nullptr,
+                 const WgradBatch *more = nullptr, int count = 1)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
     auto kern = conv3x3_wgrad_kernel<CIN, COUT, H, W, TR, IN_MODE>;
@@ -415,7 +427,15 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
     const size_t need = (size_t)grid * COUT * C::JP * sizeof(float);
     if (need > workspace_bytes)
         return fail(PPO_E_INVALID, "conv3x3_wgrad: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWgradWaves * 64), C::LDS_BYTES, st, in, dy, workspace, n_images);
+    WgradBatch batch{};
+    if (more) {
+        batch = *more;  // `count` problems, each with a workspace of workspace_bytes
+    } else {
+        batch.in[0] = in;
+        batch.dy[0] = dy;
+        batch.partial[0] = workspace;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, count), dim3(kWgradWaves * 64), C::LDS_BYTES, st, batch, n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
     if (n_slabs_out) {  // slabs only: the caller reduces later (ppo_conv3x3_wgrad_reduce_f32)
@@ -430,12 +450,14 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
 
 template <int IN_MODE>
 int dispatch_wgrad(int cin, int cout, int h, int w_, const void *in, const float *dy, float *dw, float *db,
-                   float *ws, size_t ws_bytes, int n, int accumulate, hipStream_t st, int *n_slabs_out = nullptr)
+                   float *ws, size_t ws_bytes, int n, int accumulate, hipStream_t st, int *n_slabs_out = nullptr,
+                   const WgradBatch *more = nullptr, int count = 1)
 {
 #define PPO_WGRAD_CASE(ALLOWED, CI, CO, HH, WW, TR)                                                  \
     if constexpr (ALLOWED) {                                                                         \
         if (cin == CI && cout == CO && h == HH && w_ == WW)                                          \
-            return launch_wgrad<CI, CO, HH, WW, TR, IN_MODE>(in, dy, dw, db, ws, ws_bytes, n, accumulate, st, n_slabs_out); \
+            return launch_wgrad<CI, CO, HH, WW, TR, IN_MODE>(in, dy, dw, db, ws, ws_bytes, n, accumulate, st, n_slabs_out, \
+                                                             more, count);                                   \
     }
     constexpr bool FIRST = IN_MODE != IN_RELU;
     constexpr bool UP = IN_MODE == IN_NONE;
@@ -501,6 +523,34 @@ extern "C" int ppo_conv3x3_backward_weight_slabs_f32(const void *in, int in_mode
         case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, in, dy, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_f32: unknown in_mode %d", in_mode);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *ins, int in_mode, const float *const *dys,
+                                                           void *const *workspaces, size_t workspace_bytes, int count,
+                                                           int n, int cin, int cout, int h, int w, int *n_slabs,
+                                                           void *stream)
+{
+    using namespace ppo;
+    if (n <= 0 || count < 1 || count > kWgradBatch)
+        return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_f32: n must be positive, count in 1..%d", kWgradBatch);
+    if (!ins || !dys || !workspaces || !n_slabs)
+        return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_f32: null pointer");
+    WgradBatch b{};
+    for (int k = 0; k < count; ++k) {
+        if (!ins[k] || !dys[k] || !workspaces[k])
+            return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_f32: null pointer in problem %d", k);
+        b.in[k] = ins[k];
+        b.dy[k] = dys[k];
+        b.partial[k] = static_cast<float *>(workspaces[k]);
+    }
+    hipStream_t st = as_stream(stream);
+    float *ws = b.partial[0];
+    switch (in_mode) {
+        case IN_NONE: return dispatch_wgrad<IN_NONE>(cin, cout, h, w, b.in[0], b.dy[0], nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, &b, count);
+        case IN_RELU: return dispatch_wgrad<IN_RELU>(cin, cout, h, w, b.in[0], b.dy[0], nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, &b, count);
+        case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, b.in[0], b.dy[0], nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, &b, count);
+    }
+    return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_f32: unknown in_mode %d", in_mode);
 }
 
 extern "C" int ppo_conv3x3_wgrad_reduce_f32(const ppo_wgrad_job *jobs, int n_jobs, void *stream)

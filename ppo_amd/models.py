@@ -31,6 +31,9 @@ FUSE_POOL_STACKS = int(os.environ.get("PPO_AMD_FUSE_POOL", "7"))
 WGRAD_SIDE_STREAM = int(os.environ.get("PPO_AMD_WGRAD_STREAM", "1"))
 # the slab reductions of all convolution layers in one launch at the end of the backward pass (0 = one per layer)
 WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
+# The four block convolutions of a stack share a geometry: their weight gradients go out as ONE launch (4 x the
+# workgroups, one ramp and one tail) once the stack's backward-data pass is through.  Needs WGRAD_BATCH_REDUCE.
+WGRAD_BATCH_LAUNCH = int(os.environ.get("PPO_AMD_WGRAD_BATCH_LAUNCH", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -793,6 +796,33 @@ class DualHeadNet:
                 jobs.append(_lib.WgradJob(_p(ws), _p(self.grads[wname + ".weight"]), _p(self.grads[wname + ".bias"]),
                                           n_slabs.value, cin, cout, 0))
 
+        def wgrad_blocks(problems, n, c, hh, ww):
+            """Weight gradients of a stack's block convolutions, problems = [(x, dy, wname)] (all IN_RELU, c -> c)."""
+            if not (WGRAD_BATCH_LAUNCH and WGRAD_BATCH_REDUCE) or len(problems) > 4:
+                for x, dy, wname in problems:
+                    wgrad(x, IN_RELU, dy, wname, n, c, c, hh, ww)
+                return
+            nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(c, c)
+            wss = [self._ws("wgrad_ws_" + wname, nbytes) for _x, _dy, wname in problems]
+            k = len(problems)
+            n_slabs = ctypes.c_int(0)
+            args_ = ("ppo_conv3x3_backward_weight_slabs_batch_f32", (ctypes.c_void_p * k)(*[x.data_ptr() for x, _d, _w in problems]),
+                     IN_RELU, (ctypes.c_void_p * k)(*[dy.data_ptr() for _x, dy, _w in problems]),
+                     (ctypes.c_void_p * k)(*[ws.data_ptr() for ws in wss]), nbytes, k, n, c, c, hh, ww,
+                     ctypes.addressof(n_slabs))
+            if side is None:
+                self._call(*args_)
+            else:
+                ev = self._wgrad_events[n_wgrad[0]]
+                n_wgrad[0] += 1
+                ev.record(main)  # every dy of the stack is ready
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._call(*args_)
+            for (_x, _dy, wname), ws in zip(problems, wss):
+                jobs.append(_lib.WgradJob(_p(ws), _p(self.grads[wname + ".weight"]), _p(self.grads[wname + ".bias"]),
+                                          n_slabs.value, c, c, 0))
+
         for si in reversed(range(len(sp.stacks))):
             cin, cout, hh, ww, ho, wo = sp.stacks[si]
             full_w = self._stack_full_bwd_ptrs(si, cin, cout, hh, ww) if si > 0 else None
@@ -804,13 +834,11 @@ class DualHeadNet:
                                     (f"g{si}_1_da", f"g{si}_1_in", f"g{si}_0_da", f"g{si}_0_in"))
                 dc = self._buf(f"g{si}_dc", (B, cout, hh, ww))
                 g_prev = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
-                wgrad(a1, IN_RELU, g, b1 + ".conv1", B, cout, cout, ho, wo)
                 masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p_in.data_ptr())
                 self._call("ppo_impala_stack_full_backward_f32", _p(g), full_w, masks, _p(acts[f"idx{si}"]), _p(da1), _p(g1),
                            _p(da0), _p(g0), _p(dc), _p(g_prev), B, cout, hh, ww)
-                wgrad(q0, IN_RELU, da1, b1 + ".conv0", B, cout, cout, ho, wo)
-                wgrad(a0, IN_RELU, g1, b0 + ".conv1", B, cout, cout, ho, wo)
-                wgrad(p_in, IN_RELU, da0, b0 + ".conv0", B, cout, cout, ho, wo)
+                wgrad_blocks([(a1, g, b1 + ".conv1"), (q0, da1, b1 + ".conv0"), (a0, g1, b0 + ".conv1"),
+                              (p_in, da0, b0 + ".conv0")], B, cout, ho, wo)
                 wgrad(acts[f"in{si}"], IN_NONE, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
                 g = g_prev
                 continue
@@ -821,27 +849,35 @@ class DualHeadNet:
                 p_in, a0, q0, a1 = acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"]
                 da1, g1, da0, g0 = (self._buf(nm, (B, cout, ho, wo)) for nm in
                                     (f"g{si}_1_da", f"g{si}_1_in", f"g{si}_0_da", f"g{si}_0_in"))
-                wgrad(a1, IN_RELU, g, b1 + ".conv1", B, cout, cout, ho, wo)  # its dy is the incoming gradient
                 masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p_in.data_ptr())
                 self._call("ppo_impala_stack_tail_backward_f32", _p(g), tail_w, masks, _p(da1), _p(g1), _p(da0), _p(g0),
                            B, cout, ho, wo)
-                wgrad(q0, IN_RELU, da1, b1 + ".conv0", B, cout, cout, ho, wo)
-                wgrad(a0, IN_RELU, g1, b0 + ".conv1", B, cout, cout, ho, wo)
-                wgrad(p_in, IN_RELU, da0, b0 + ".conv0", B, cout, cout, ho, wo)
+                wgrad_blocks([(a1, g, b1 + ".conv1"), (q0, da1, b1 + ".conv0"), (a0, g1, b0 + ".conv1"),
+                              (p_in, da0, b0 + ".conv0")], B, cout, ho, wo)
                 g = g0
+            defer = WGRAD_BATCH_LAUNCH and WGRAD_BATCH_REDUCE and sp.n_block * 2 <= 4
+            problems = []
             for bi in (reversed(range(sp.n_block)) if tail_w is None else ()):
                 base = f"encoder.stacks.{si}.blocks.{bi}"
                 q_in, a = acts[f"q{si}_{bi}_in"], acts[f"a{si}_{bi}"]
                 # g = d loss / d (block output);  block: out = q_in + conv1(relu(conv0(relu(q_in))))
-                wgrad(a, IN_RELU, g, base + ".conv1", B, cout, cout, ho, wo)
+                if defer:
+                    problems.append((a, g, base + ".conv1"))
+                else:
+                    wgrad(a, IN_RELU, g, base + ".conv1", B, cout, cout, ho, wo)
                 da = self._buf(f"g{si}_{bi}_da", (B, cout, ho, wo))
                 self._call(self._bwd_data_fn(base + ".conv1"), _p(g), _p(self._bwd_w(base + ".conv1")), _p(a), None,
                            _p(da), B, cout, cout, ho, wo)
-                wgrad(q_in, IN_RELU, da, base + ".conv0", B, cout, cout, ho, wo)
+                if defer:
+                    problems.append((q_in, da, base + ".conv0"))
+                else:
+                    wgrad(q_in, IN_RELU, da, base + ".conv0", B, cout, cout, ho, wo)
                 gn = self._buf(f"g{si}_{bi}_in", (B, cout, ho, wo))
                 self._call(self._bwd_data_fn(base + ".conv0"), _p(da), _p(self._bwd_w(base + ".conv0")), _p(q_in),
                            _p(g), _p(gn), B, cout, cout, ho, wo)
                 g = gn
+            if problems:
+                wgrad_blocks(problems, B, cout, ho, wo)
             # max-pool backward, then the stack's first convolution
             dc = self._buf(f"g{si}_dc", (B, cout, hh, ww))
             self._call("ppo_maxpool3x3s2_backward_f32", _p(g), _p(acts[f"idx{si}"]), _p(dc), B, cout, hh, ww)
