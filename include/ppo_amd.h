@@ -186,6 +186,15 @@ int ppo_conv3x3_backward_weight_slabs_f32(const void *in, int in_mode, const flo
 int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *ins, int in_mode, const float *const *dys,
                                                 void *const *workspaces, size_t workspace_bytes, int count, int n, int cin,
                                                 int cout, int h, int w, int *n_slabs, void *stream);
+/* A stack's FIRST convolution with its dy taken from the pooled gradient: dy = ppo_maxpool3x3s2_backward_f32(g, argmax)
+ * is formed band by band inside the kernel (g [n,cout,h/2,w/2], argmax uint8 likewise), so the pre-pool gradient map
+ * never exists in HBM.  Same slabs as the max-pool backward launch followed by ppo_conv3x3_backward_weight_slabs_f32.
+ * Only where nothing else reads that map (the first stack: no backward-data into the observations); geometries per
+ * ppo_conv3x3_backward_weight_pooled_supported. */
+int ppo_conv3x3_backward_weight_pooled_supported(int cin, int cout, int h, int w);
+int ppo_conv3x3_backward_weight_slabs_pooled_f32(const void *in, int in_mode, const float *g, const uint8_t *argmax,
+                                                 void *workspace, size_t workspace_bytes, int n, int cin, int cout, int h,
+                                                 int w, int *n_slabs, void *stream);
 int ppo_conv3x3_wgrad_reduce_f32(const ppo_wgrad_job *jobs, int n_jobs, void *stream);
 
 /*

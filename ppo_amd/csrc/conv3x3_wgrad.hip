@@ -135,11 +135,12 @@ __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, con
 constexpr int kWgradBatch = 4;
 struct WgradBatch {
     const void *in[kWgradBatch];
-    const float *dy[kWgradBatch];
+    const float *dy[kWgradBatch];  // DY_POOLED: the POOLED gradient g [n, COUT, H/2, W/2] ...
     float *partial[kWgradBatch];
+    const uint8_t *argmax;         // ... and the pooling's argmax (problem 0 only): dy = maxpool_backward(g, argmax)
 };
 
-template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
+template <int CIN, int COUT, int H, int W, int TR, int IN_MODE, bool DY_POOLED = false>
 __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBatch batch, int n_images)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
@@ -192,7 +193,10 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
             stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, bx, tid);
         else
             stage_band_dma<CIN, H, W, C::ROWS, C::PWX, C::XPLANE, 1, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
-        stage_band_dma<COUT, H, W, TR, C::PWD, C::DPLANE, 0, kWgradWaves>(dy, img, y0, bd, tid);
+        if constexpr (DY_POOLED)
+            stage_dy_pooled<COUT, H, W, TR, C::PWD, C::DPLANE, kWgradWaves>(dy, batch.argmax, img, y0, bd, tid);
+        else
+            stage_band_dma<COUT, H, W, TR, C::PWD, C::DPLANE, 0, kWgradWaves>(dy, img, y0, bd, tid);
     };
     constexpr bool RELU = IN_MODE == IN_RELU;
     if constexpr (C::NBUF == 2) {
@@ -402,13 +406,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_jobs_kernel(ReduceJo
     }
 }
 
-template <int CIN, int COUT, int H, int W, int TR, int IN_MODE>
+template <int CIN, int COUT, int H, int W, int TR, int IN_MODE, bool DY_POOLED = false>
 int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *workspace, size_t workspace_bytes,
                  int n_images, int accumulate, hipStream_t st, int *n_slabs_out = nullptr,
-                 const WgradBatch *more = nullptr, int count = 1)
+                 const WgradBatch *more = nullptr, int count = 1, const uint8_t *argmax = nullptr)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
-    auto kern = conv3x3_wgrad_kernel<CIN, COUT, H, W, TR, IN_MODE>;
+    auto kern = conv3x3_wgrad_kernel<CIN, COUT, H, W, TR, IN_MODE, DY_POOLED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -435,6 +439,7 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
         batch.dy[0] = dy;
         batch.partial[0] = workspace;
     }
+    batch.argmax = argmax;
     hipLaunchKernelGGL(kern, dim3(grid, count), dim3(kWgradWaves * 64), C::LDS_BYTES, st, batch, n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
@@ -451,8 +456,22 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
 template <int IN_MODE>
 int dispatch_wgrad(int cin, int cout, int h, int w_, const void *in, const float *dy, float *dw, float *db,
                    float *ws, size_t ws_bytes, int n, int accumulate, hipStream_t st, int *n_slabs_out = nullptr,
-                   const WgradBatch *more = nullptr, int count = 1)
+                   const WgradBatch *more = nullptr, int count = 1, const uint8_t *argmax = nullptr)
 {
+#define PPO_WGRAD_POOLED_CASE(CI, CO, HH, WW, TR)                                                    \
+    if constexpr (IN_MODE != IN_RELU) {                                                              \
+        if (argmax && cin == CI && cout == CO && h == HH && w_ == WW)                                \
+            return launch_wgrad<CI, CO, HH, WW, TR, IN_MODE, true>(in, dy, dw, db, ws, ws_bytes, n, accumulate, st, n_slabs_out, \
+                                                                   nullptr, 1, argmax);              \
+    }
+    PPO_WGRAD_POOLED_CASE(4, 16, 84, 84, 6)
+    PPO_WGRAD_POOLED_CASE(5, 16, 84, 84, 6)
+    PPO_WGRAD_POOLED_CASE(3, 16, 64, 64, 8)
+    PPO_WGRAD_POOLED_CASE(4, 16, 64, 64, 8)
+#undef PPO_WGRAD_POOLED_CASE
+    if (argmax)
+        return fail(PPO_E_INVALID, "conv3x3_wgrad: no pooled-gradient kernel for cin=%d cout=%d h=%d w=%d in_mode=%d", cin,
+                    cout, h, w_, IN_MODE);
 #define PPO_WGRAD_CASE(ALLOWED, CI, CO, HH, WW, TR)                                                  \
     if constexpr (ALLOWED) {                                                                         \
         if (cin == CI && cout == CO && h == HH && w_ == WW)                                          \
@@ -551,6 +570,29 @@ extern "C" int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *in
         case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, b.in[0], b.dy[0], nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, &b, count);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_f32: unknown in_mode %d", in_mode);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_slabs_pooled_f32(const void *in, int in_mode, const float *g,
+                                                            const uint8_t *argmax, void *workspace, size_t workspace_bytes,
+                                                            int n, int cin, int cout, int h, int w, int *n_slabs,
+                                                            void *stream)
+{
+    using namespace ppo;
+    if (n <= 0) return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_pooled_f32: n must be positive");
+    if (!in || !g || !argmax || !workspace || !n_slabs)
+        return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_pooled_f32: null pointer");
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(workspace);
+    switch (in_mode) {
+        case IN_NONE: return dispatch_wgrad<IN_NONE>(cin, cout, h, w, in, g, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, nullptr, 1, argmax);
+        case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, in, g, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, nullptr, 1, argmax);
+    }
+    return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_pooled_f32: in_mode %d has no pooled-gradient kernel", in_mode);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_pooled_supported(int cin, int cout, int h, int w)
+{
+    return cout == 16 && ((h == 84 && w == 84 && (cin == 4 || cin == 5)) || (h == 64 && w == 64 && (cin == 3 || cin == 4)));
 }
 
 extern "C" int ppo_conv3x3_wgrad_reduce_f32(const ppo_wgrad_job *jobs, int n_jobs, void *stream)

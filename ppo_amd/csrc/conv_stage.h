@@ -116,6 +116,50 @@ __device__ __forceinline__ void stage_band_dma(const float *__restrict__ src, in
     }
 }
 
+// The dy band of a stack's FIRST convolution computed from the pooled gradient instead of read from HBM:
+//   dc = maxpool3x3s2_backward(g, argmax)   (even H, W: the 2x2-block form and summation order of maxpool_bwd2x2_kernel)
+// written in stage_band_dma's HALO = 0 layout, s_dst[c * PLANE + r * PW + x].  One thread per 2x2 block of the band
+// (4 (argmax, g) pairs -> 4 values).  The pre-pool gradient map (the largest tensor of the backward pass: 115 MB at
+// 84x84x16x256) is then never written or read.
+template <int C, int H, int W, int TR, int PW, int PLANE, int NWAVES>
+__device__ __forceinline__ void stage_dy_pooled(const float *__restrict__ g, const uint8_t *__restrict__ argmax, int img,
+                                                int y0, float *__restrict__ s_dst, int tid)
+{
+    static_assert(H % 2 == 0 && W % 2 == 0 && TR % 2 == 0 && H % TR == 0, "even maps, whole bands");
+    constexpr int HO = H / 2, WO = W / 2, JB = TR / 2, NBLK = C * JB * WO;
+    for (int b = tid; b < NBLK; b += NWAVES * 64) {
+        const int c = b / (JB * WO), rem = b % (JB * WO);
+        const int jb = rem / WO, k = rem % WO;
+        const int j = y0 / 2 + jb;
+        const size_t t = ((size_t)(img * C + c) * HO + j) * WO + k;
+        const float *gp = g + t;
+        const uint8_t *a = argmax + t;
+        const bool right = k + 1 < WO, down = j + 1 < HO;
+        const int t00 = a[0];
+        const float g00 = gp[0];
+        const int t01 = right ? a[1] : -1;
+        const float g01 = right ? gp[1] : 0.f;
+        const int t10 = down ? a[WO] : -1;
+        const float g10 = down ? gp[WO] : 0.f;
+        const int t11 = (right && down) ? a[WO + 1] : -1;
+        const float g11 = (right && down) ? gp[WO + 1] : 0.f;
+        const float r00 = (t00 == 4 ? g00 : 0.f);
+        float r01 = (t00 == 5 ? g00 : 0.f);
+        r01 += (t01 == 3 ? g01 : 0.f);
+        float r10 = (t00 == 7 ? g00 : 0.f);
+        r10 += (t10 == 1 ? g10 : 0.f);
+        float r11 = (t00 == 8 ? g00 : 0.f);
+        r11 += (t01 == 6 ? g01 : 0.f);
+        r11 += (t10 == 2 ? g10 : 0.f);
+        r11 += (t11 == 0 ? g11 : 0.f);
+        float *d = s_dst + c * PLANE + (2 * jb) * PW + 2 * k;
+        d[0] = r00;
+        d[1] = r01;
+        d[PW] = r10;
+        d[PW + 1] = r11;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // "Flat" band layout: a channel plane holds the band rows back to back with the IMAGE's row stride,
 //   s_dst[c * PLANE + G + r * W + x] = f(src[img][c][y0 + r - 1][x]),  r < ROWS (one halo row above / below),

@@ -34,6 +34,11 @@ WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
 # The four block convolutions of a stack share a geometry: their weight gradients go out as ONE launch (4 x the
 # workgroups, one ramp and one tail) once the stack's backward-data pass is through.  Needs WGRAD_BATCH_REDUCE.
 WGRAD_BATCH_LAUNCH = int(os.environ.get("PPO_AMD_WGRAD_BATCH_LAUNCH", "1"))
+# The first stack's max-pool backward is folded into its first convolution's weight-gradient kernel (the only reader of
+# that 84x84 gradient map: nothing back-propagates into the observations).  Needs WGRAD_BATCH_REDUCE.  Measured: the
+# max-pool backward launch (37 us) goes, the weight-gradient kernel grows by ~30 us (scalar gathers of 4 (argmax, g)
+# pairs per 2x2 block): -5 us per step net and a 115 MB tensor less; wider gathers are the follow-up.
+WGRAD_POOLED_DY = int(os.environ.get("PPO_AMD_WGRAD_POOLED_DY", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -772,13 +777,18 @@ class DualHeadNet:
 
         jobs = []  # deferred slab reductions: one launch for all layers at the end of the pass
 
-        def wgrad(x, mode, dy, wname, n, cin, cout, hh, ww):
+        def wgrad(x, mode, dy, wname, n, cin, cout, hh, ww, argmax=None):
+            """argmax given: dy is the POOLED gradient and the kernel forms max-pool backward itself."""
             nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
             if WGRAD_BATCH_REDUCE:
                 ws = self._ws("wgrad_ws_" + wname, nbytes)  # per layer: the slabs live until the batched reduction
                 n_slabs = ctypes.c_int(0)
-                args_ = ("ppo_conv3x3_backward_weight_slabs_f32", _p(x), mode, _p(dy), _p(ws), nbytes, n, cin, cout,
-                         hh, ww, ctypes.addressof(n_slabs))
+                if argmax is not None:
+                    args_ = ("ppo_conv3x3_backward_weight_slabs_pooled_f32", _p(x), mode, _p(dy), _p(argmax), _p(ws),
+                             nbytes, n, cin, cout, hh, ww, ctypes.addressof(n_slabs))
+                else:
+                    args_ = ("ppo_conv3x3_backward_weight_slabs_f32", _p(x), mode, _p(dy), _p(ws), nbytes, n, cin, cout,
+                             hh, ww, ctypes.addressof(n_slabs))
             else:
                 ws = self._ws("wgrad_ws", nbytes)
                 args_ = ("ppo_conv3x3_backward_weight_f32", _p(x), mode, _p(dy), _p(self.grads[wname + ".weight"]),
@@ -879,10 +889,15 @@ class DualHeadNet:
             if problems:
                 wgrad_blocks(problems, B, cout, ho, wo)
             # max-pool backward, then the stack's first convolution
-            dc = self._buf(f"g{si}_dc", (B, cout, hh, ww))
-            self._call("ppo_maxpool3x3s2_backward_f32", _p(g), _p(acts[f"idx{si}"]), _p(dc), B, cout, hh, ww)
             x_in = acts[f"in{si}"]
             mode = IN_NONE if si > 0 else (IN_U8 if x_in.dtype == torch.uint8 else IN_NONE)
+            if si == 0 and WGRAD_POOLED_DY and WGRAD_BATCH_REDUCE \
+                    and lib.ppo_conv3x3_backward_weight_pooled_supported(cin, cout, hh, ww):
+                # nothing else reads this stack's pre-pool gradient: the weight-gradient kernel forms it band by band
+                wgrad(x_in, mode, g, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww, argmax=acts[f"idx{si}"])
+                continue
+            dc = self._buf(f"g{si}_dc", (B, cout, hh, ww))
+            self._call("ppo_maxpool3x3s2_backward_f32", _p(g), _p(acts[f"idx{si}"]), _p(dc), B, cout, hh, ww)
             wgrad(x_in, mode, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
             if si > 0:
                 g = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))

@@ -198,12 +198,14 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
         pac = logp.gather(1, actions.long()[:, None])[:, 0].contiguous()
         adv, ret = torch.randn(B, device="cuda", generator=g), torch.randn(B, 1, device="cuda", generator=g)
         monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
+        monkeypatch.setattr(models, "WGRAD_POOLED_DY", 1)     # first stack's pool backward inside its weight-gradient kernel
         monkeypatch.setattr(models, "WGRAD_BATCH_LAUNCH", 1)  # one weight-gradient launch per stack's blocks ...
         acts_a = a.encode(x, train=True)
         saved = {k: acts_a[k].clone() for k in ("q1_0_in", "a1_0", "q1_1_in", "a1_1", "in2", "idx2",
                                                 "q2_0_in", "a2_0", "q2_1_in", "a2_1", "flat")}
         a.ppo_minibatch(x, actions, pac, logp, adv, ret)
         monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
+        monkeypatch.setattr(models, "WGRAD_POOLED_DY", 0)
         monkeypatch.setattr(models, "WGRAD_BATCH_LAUNCH", 0)  # ... against one per convolution
         acts_b = b.encode(x, train=True)
         for k, v in saved.items():
