@@ -193,10 +193,13 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
             stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, bx, tid);
         else
             stage_band_dma<CIN, H, W, C::ROWS, C::PWX, C::XPLANE, 1, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
-        if constexpr (DY_POOLED)
+        if constexpr (DY_POOLED) {
+            static_assert(C::LDS_X % 2 == 0 && C::LDS_BUF % 2 == 0, "stage_dy_pooled stores float2 pairs");
             stage_dy_pooled<COUT, H, W, TR, C::PWD, C::DPLANE, kWgradWaves>(dy, batch.argmax, img, y0, bd, tid);
-        else
+        }
+        else {
             stage_band_dma<COUT, H, W, TR, C::PWD, C::DPLANE, 0, kWgradWaves>(dy, img, y0, bd, tid);
+        }
     };
     constexpr bool RELU = IN_MODE == IN_RELU;
     if constexpr (C::NBUF == 2) {

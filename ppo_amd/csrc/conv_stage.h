@@ -126,37 +126,62 @@ __device__ __forceinline__ void stage_dy_pooled(const float *__restrict__ g, con
                                                 int y0, float *__restrict__ s_dst, int tid)
 {
     static_assert(H % 2 == 0 && W % 2 == 0 && TR % 2 == 0 && H % TR == 0, "even maps, whole bands");
-    constexpr int HO = H / 2, WO = W / 2, JB = TR / 2, NBLK = C * JB * WO;
-    for (int b = tid; b < NBLK; b += NWAVES * 64) {
-        const int c = b / (JB * WO), rem = b % (JB * WO);
-        const int jb = rem / WO, k = rem % WO;
+    constexpr int HO = H / 2, WO = W / 2, JB = TR / 2;
+    static_assert(WO % 2 == 0 && (HO * WO) % 2 == 0 && PLANE % 2 == 0 && PW % 2 == 0, "8-byte aligned pairs");
+    // a thread takes TWO neighbouring 2x2 blocks (pooled columns k0, k0 + 1): the windows that can select their
+    // elements are (j, k0 .. k0 + 2) and (j + 1, k0 .. k0 + 2) -> per row one float2 + one float of g, one ushort + one
+    // byte of argmax (8 loads for 8 outputs; one block per thread needs 8 loads for 4)
+    constexpr int KP = WO / 2, NTASK = C * JB * KP;
+    for (int b = tid; b < NTASK; b += NWAVES * 64) {
+        const int c = b / (JB * KP), rem = b % (JB * KP);
+        const int jb = rem / KP, k0 = 2 * (rem % KP);
         const int j = y0 / 2 + jb;
-        const size_t t = ((size_t)(img * C + c) * HO + j) * WO + k;
-        const float *gp = g + t;
-        const uint8_t *a = argmax + t;
-        const bool right = k + 1 < WO, down = j + 1 < HO;
-        const int t00 = a[0];
-        const float g00 = gp[0];
-        const int t01 = right ? a[1] : -1;
-        const float g01 = right ? gp[1] : 0.f;
-        const int t10 = down ? a[WO] : -1;
-        const float g10 = down ? gp[WO] : 0.f;
-        const int t11 = (right && down) ? a[WO + 1] : -1;
-        const float g11 = (right && down) ? gp[WO + 1] : 0.f;
-        const float r00 = (t00 == 4 ? g00 : 0.f);
-        float r01 = (t00 == 5 ? g00 : 0.f);
-        r01 += (t01 == 3 ? g01 : 0.f);
-        float r10 = (t00 == 7 ? g00 : 0.f);
-        r10 += (t10 == 1 ? g10 : 0.f);
-        float r11 = (t00 == 8 ? g00 : 0.f);
-        r11 += (t01 == 6 ? g01 : 0.f);
-        r11 += (t10 == 2 ? g10 : 0.f);
-        r11 += (t11 == 0 ? g11 : 0.f);
-        float *d = s_dst + c * PLANE + (2 * jb) * PW + 2 * k;
-        d[0] = r00;
-        d[1] = r01;
-        d[PW] = r10;
-        d[PW + 1] = r11;
+        const size_t t = ((size_t)(img * C + c) * HO + j) * WO + k0;
+        const bool right = k0 + 2 < WO, down = j + 1 < HO;
+        const float2 ga = *reinterpret_cast<const float2 *>(g + t);
+        const unsigned aa = *reinterpret_cast<const unsigned short *>(argmax + t);
+        const float ga2 = right ? g[t + 2] : 0.f;
+        const int ta2 = right ? argmax[t + 2] : -1;
+        float2 gb = make_float2(0.f, 0.f);
+        unsigned ab = 0xffffu;
+        float gb2 = 0.f;
+        int tb2 = -1;
+        if (down) {
+            gb = *reinterpret_cast<const float2 *>(g + t + WO);
+            ab = *reinterpret_cast<const unsigned short *>(argmax + t + WO);
+            if (right) {
+                gb2 = g[t + WO + 2];
+                tb2 = argmax[t + WO + 2];
+            }
+        }
+        const int ta0 = aa & 0xff, ta1 = aa >> 8;
+        const int tb0 = down ? (int)(ab & 0xff) : -1, tb1 = down ? (int)(ab >> 8) : -1;
+        // block k0: windows (j,k0) (j,k0+1) (j+1,k0) (j+1,k0+1); block k0+1: (j,k0+1) (j,k0+2) (j+1,k0+1) (j+1,k0+2);
+        // summation order per element as maxpool_bwd2x2_kernel
+        float2 top0, top1, bot0, bot1;
+        top0.x = (ta0 == 4 ? ga.x : 0.f);
+        top0.y = (ta0 == 5 ? ga.x : 0.f);
+        top0.y += (ta1 == 3 ? ga.y : 0.f);
+        bot0.x = (ta0 == 7 ? ga.x : 0.f);
+        bot0.x += (tb0 == 1 ? gb.x : 0.f);
+        bot0.y = (ta0 == 8 ? ga.x : 0.f);
+        bot0.y += (ta1 == 6 ? ga.y : 0.f);
+        bot0.y += (tb0 == 2 ? gb.x : 0.f);
+        bot0.y += (tb1 == 0 ? gb.y : 0.f);
+        top1.x = (ta1 == 4 ? ga.y : 0.f);
+        top1.y = (ta1 == 5 ? ga.y : 0.f);
+        top1.y += (ta2 == 3 ? ga2 : 0.f);
+        bot1.x = (ta1 == 7 ? ga.y : 0.f);
+        bot1.x += (tb1 == 1 ? gb.y : 0.f);
+        bot1.y = (ta1 == 8 ? ga.y : 0.f);
+        bot1.y += (ta2 == 6 ? ga2 : 0.f);
+        bot1.y += (tb1 == 2 ? gb.y : 0.f);
+        bot1.y += (tb2 == 0 ? gb2 : 0.f);
+        float *d = s_dst + c * PLANE + (2 * jb) * PW + 2 * k0;
+        *reinterpret_cast<float2 *>(d) = top0;
+        *reinterpret_cast<float2 *>(d + 2) = top1;
+        *reinterpret_cast<float2 *>(d + PW) = bot0;
+        *reinterpret_cast<float2 *>(d + PW + 2) = bot1;
     }
 }
 

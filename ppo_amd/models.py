@@ -36,8 +36,8 @@ WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
 WGRAD_BATCH_LAUNCH = int(os.environ.get("PPO_AMD_WGRAD_BATCH_LAUNCH", "1"))
 # The first stack's max-pool backward is folded into its first convolution's weight-gradient kernel (the only reader of
 # that 84x84 gradient map: nothing back-propagates into the observations).  Needs WGRAD_BATCH_REDUCE.  Measured: the
-# max-pool backward launch (37 us) goes, the weight-gradient kernel grows by ~30 us (scalar gathers of 4 (argmax, g)
-# pairs per 2x2 block): -5 us per step net and a 115 MB tensor less; wider gathers are the follow-up.
+# max-pool backward launch (37 us) goes, the weight-gradient kernel grows by ~20 us (it gathers (argmax, g) pairs
+# instead of streaming the map in by LDS-DMA): -15 us per step net and a 115 MB tensor less.
 WGRAD_POOLED_DY = int(os.environ.get("PPO_AMD_WGRAD_POOLED_DY", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
