@@ -459,6 +459,11 @@ void ppo_synth_env_destroy(void *env);
 int ppo_synth_env_reset(void *env, uint8_t *obs_out);
 int ppo_synth_env_step(void *env, const int32_t *actions, uint8_t *obs_out, float *reward_out, uint8_t *done_out,
                        int32_t *time_out, float *ep_score_out, int32_t *ep_len_out);
+/* Checkpointing, the counterpart of the worker envs' save_state / restore_state (rl/hybridVecEnv.py:84-105,
+ * rl/utils.py:977-1038): per-env generator step count [n] i64, steps since reset [n] i32, running episode score
+ * [n] f32.  set_state also rewrites obs_out [n_envs, obs_bytes] with the observation those counters imply. */
+int ppo_synth_env_get_state(void *env, int64_t *steps_out, int32_t *time_out, float *score_out);
+int ppo_synth_env_set_state(void *env, const int64_t *steps, const int32_t *time, const float *score, uint8_t *obs_out);
 
 #ifdef __cplusplus
 }

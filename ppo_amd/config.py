@@ -90,6 +90,8 @@ class EnvConfig(_Group):  # rl/config.py:495-603
         ("timeout", int, 0, "episode step limit (0 = env default)"),
         ("synthetic_done_prob", float, 0.01, "synthetic env: per-step termination probability"),
         ("synthetic_threads", int, 8, "synthetic env: host threads generating observations"),
+        ("synthetic_actions", int, 0, "synthetic env: size of the action set (0 = 6, the Pong-shaped default)"),
+        ("synthetic_shape", str, None, "synthetic env: observation shape 'C,H,W' (default 4,84,84; procgen-shaped: 3,64,64)"),
         ("pipeline_parts", int, 2, "split the envs into this many groups so host stepping overlaps the GPU policy step"),
     )
 
@@ -174,8 +176,13 @@ class Config:
         self.output_folder = "./"
         self.experiment_name = "Run"
         self.run_name = "run"
-        self.restore = "never"
-        self.checkpoint_every = int(10e6)
+        self.restore = "auto"          # :720
+        self.initial_model = None      # :728
+        self.checkpoint_every = int(10e6)  # :752
+        self.save_checkpoints = True   # :736
+        self.save_initial_checkpoint = False  # :737
+        self.save_early_checkpoint = False    # :738
+        self.debug_print_freq = 60     # DebugConfig.print_freq
         self.checkpoint_compression = True  # :726
         self.workers = -1              # :722
         self.threads = 2               # :723
@@ -239,7 +246,13 @@ class Config:
         a("--experiment_name", type=str, default=self.experiment_name)
         a("--run_name", type=str, default=self.run_name)
         a("--restore", type=str, default=self.restore, help="[never|auto|always]")
+        a("--initial_model", type=str, default=None, help="checkpoint (in log_folder) to start from at step 0")
+        a("--log_folder", type=str, default=None)
         a("--checkpoint_every", type=int, default=self.checkpoint_every)
+        a("--save_checkpoints", type=str2bool, nargs="?", const=True, default=True)
+        a("--save_initial_checkpoint", type=str2bool, nargs="?", const=True, default=False)
+        a("--save_early_checkpoint", type=str2bool, nargs="?", const=True, default=False)
+        a("--debug_print_freq", type=int, default=self.debug_print_freq)
         a("--checkpoint_compression", type=str2bool, nargs="?", const=True, default=True)
         a("--workers", type=int, default=self.workers)
         a("--threads", type=int, default=self.threads)
@@ -272,8 +285,10 @@ class Config:
             raise ValueError("Invalid clip_mode.")
         if self.tvf.gamma is None:
             self.tvf.gamma = self.gamma
-        if self.log_folder is None:
-            self.log_folder = self.output_folder
+        if self.restore in ("True", "true", True):  # rl/config.py:810-812
+            self.restore = "always"
+        if self.restore not in ("always", "never", "auto"):
+            raise ValueError(f"Expecting {self.restore} to be one of ['always', 'never', 'auto']")
 
     def flatten(self):
         d = {k: v for k, v in vars(self).items() if not k.startswith("_") and not isinstance(v, _Group)}

@@ -214,3 +214,30 @@ extern "C" int ppo_synth_env_step(void *h, const int32_t *actions, uint8_t *obs_
     e->dispatch();
     return PPO_OK;
 }
+
+// Checkpointing (rl/hybridVecEnv.py:84-105 save_state / restore_state of the worker envs): the generator state of an
+// env is its step count; time / score are the running episode's statistics.
+extern "C" int ppo_synth_env_get_state(void *h, int64_t *steps_out, int32_t *time_out, float *score_out)
+{
+    auto *e = static_cast<SynthEnv *>(h);
+    if (!e || !steps_out || !time_out || !score_out) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_get_state: null");
+    std::memcpy(steps_out, e->steps.data(), sizeof(int64_t) * e->n_envs);
+    std::memcpy(time_out, e->time.data(), sizeof(int32_t) * e->n_envs);
+    std::memcpy(score_out, e->score.data(), sizeof(float) * e->n_envs);
+    return PPO_OK;
+}
+
+extern "C" int ppo_synth_env_set_state(void *h, const int64_t *steps, const int32_t *time, const float *score,
+                                       uint8_t *obs_out)
+{
+    auto *e = static_cast<SynthEnv *>(h);
+    if (!e || !steps || !time || !score || !obs_out) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_set_state: null");
+    for (int i = 0; i < e->n_envs; ++i)
+        if (steps[i] < 0 || time[i] < 0) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_set_state: negative counter");
+    std::memcpy(e->steps.data(), steps, sizeof(int64_t) * e->n_envs);
+    std::memcpy(e->time.data(), time, sizeof(int32_t) * e->n_envs);
+    std::memcpy(e->score.data(), score, sizeof(float) * e->n_envs);
+    e->obs = obs_out;  // the current observation is a function of (seed, env, steps): regenerate it
+    for (int i = 0; i < e->n_envs; ++i) e->fill_obs(i);
+    return PPO_OK;
+}

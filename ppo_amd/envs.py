@@ -25,6 +25,11 @@ def get_env_spec():
     if t == "procgen" and args.env.embed_time:
         shape = (4, 64, 64)
     n_actions = {"atari": 6, "procgen": 15, "synthetic": 6, "classic": 2}.get(t, 6)
+    if t == "synthetic":  # the benchmark workload in the shape of any config (BASELINE.json configs[1..3])
+        if args.env.synthetic_shape:
+            shape = tuple(int(v) for v in str(args.env.synthetic_shape).split(","))
+        if args.env.synthetic_actions > 0:
+            n_actions = int(args.env.synthetic_actions)
     return shape, n_actions
 
 
@@ -38,9 +43,10 @@ def _classic_env_fns(N, base_seed, first):
 def _moments_sync(moments):
     """Sum the reward normaliser's per-step moments over data-parallel ranks."""
     import torch
-    t = torch.from_numpy(np.asarray(moments, np.float64))
+    t = torch.from_numpy(np.asarray(moments, np.float64).copy())
     if parallel.world_size() > 1:
-        t = t.cuda()
+        on_gpu = parallel.backend_name() == "nccl"  # RCCL reduces device buffers; gloo (CPU tests) host ones
+        t = t.cuda() if on_gpu else t
         parallel.allreduce_sum_(t)
         t = t.cpu()
     return t.numpy()

@@ -304,6 +304,7 @@ class DualHeadNet:
         self._rec = None   # launch recorder (see encode)
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
+        self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self._build_packed_weights()
         self._adam_step = 0
@@ -355,6 +356,12 @@ class DualHeadNet:
             self.g_b_heads = self.grad[o:o + self.nh]
         else:
             self.b_heads = self.g_b_heads = None
+
+    @property
+    def early_grad_offset(self) -> int:
+        """Offset in the flat gradient from which everything (dense layer, heads, log_std) is written by the first
+        launches of a backward pass; [0, offset) are the convolution gradients, final only at its end."""
+        return self._offsets["encoder.dense.weight"][0] if self.encoder_kind == "impala" else 0
 
     def n_parameters(self) -> int:
         return sum(int(np.prod(s)) for _, s in self._offsets.values())
@@ -772,6 +779,10 @@ class DualHeadNet:
         if side is not None:
             side.wait_stream(main)  # dh is complete
         self._linear_backward(flat, sp.flat, "encoder.dense", dh, g, relu_x=1, mask=flat, side=side)
+        if self.grad_ready_hook is not None:
+            # dense + head gradients (the tail of the flat buffer from `early_grad_offset` on) are final once the
+            # launches queued so far on this stream have run: a data-parallel reducer ships them under the rest
+            self.grad_ready_hook(side if side is not None else main)
 
         n_wgrad = [0]
 
@@ -994,8 +1005,9 @@ class DualHeadNet:
         self._call("ppo_gaussian_loss_f32", _p(o), B, self.nh, self.n_actions, vh, _p(actions), _p(old_log_pac),
                    _p(advantages), _p(returns), _p(self.params["log_std"]), float(eps_clip), float(vf_coef),
                    float(loss_scale) / B, _p(dheads), _p(rows), _p(stats), _p(index))
-        self.backward(acts, dheads)
+        # log_std's gradient first: it sits in the early data-parallel bucket, which leaves during the backward pass
         self._call("ppo_colsum_f32", _p(rows), B, self.n_actions, self.n_actions, _p(self.grads["log_std"]), 0)
+        self.backward(acts, dheads)
         return stats
 
     def value_minibatch(self, prev_state, returns=None, tvf_returns=None, tvf_weights=None, vf_coef=0.5,

@@ -145,6 +145,43 @@ class Runner:
         self._step_events = []
         self._phase_stats = {}
         self.timers = {}
+        self._reducers = {}
+        if self.world > 1:
+            self.sync_replicas()
+            for net in {id(n): n for n in (self.policy_net, self.value_net)}.values():
+                red = parallel.GradReducer(net.grad, net.early_grad_offset)
+                self._reducers[id(net)] = red
+                net.grad_ready_hook = red.early
+
+    def sync_replicas(self):
+        """Data-parallel ranks must hold the same model: the only per-step exchange is the gradient all-reduce, so
+        replicas that start apart stay apart, silently.  Parameters, Adam moments and the observation normaliser
+        are broadcast from rank 0 (each rank initialised from its own process RNG when --seed is unset, and a
+        restored checkpoint is read by every rank on its own), then a digest is compared across ranks."""
+        nets = list({id(n): n for n in (self.policy_net, self.value_net)}.values())
+        tensors = []
+        for net in nets:
+            tensors.append(net.flat)
+            for t in (net.exp_avg, net.exp_avg_sq):
+                if t is not None:
+                    tensors.append(t)
+        if self.distil_optimizer is not None and self.distil_optimizer.state.exp_avg is not None:
+            tensors += [self.distil_optimizer.state.exp_avg, self.distil_optimizer.state.exp_avg_sq]
+        norm = self.model.obs_norm
+        if norm is not None:
+            tensors += [norm.mean, norm.var, norm.mu, norm.std]
+        for t in tensors:
+            parallel.broadcast_(t)
+        for net in nets:
+            net.mark_weights_changed()
+        counters = torch.tensor([float(n._adam_step) for n in nets] + [float(norm.count) if norm is not None else 0.0],
+                                dtype=torch.float64, device=self.device)
+        parallel.broadcast_(counters)
+        for n, c in zip(nets, counters[:len(nets)].tolist()):
+            n._adam_step = int(c)
+        if norm is not None:
+            norm.count = float(counters[-1])
+        return parallel.assert_identical_across_ranks(tensors, "model replicas")
 
     # ------------------------------------------------------------------ helpers
     def _call(self, fn_name, *a):
@@ -411,6 +448,7 @@ class Runner:
         for s_ in streams:
             if s_ is not main:
                 main.wait_stream(s_)
+        main.wait_stream(copy_stream)  # the graph path's last all_obs rows are written by D2D copies queued there
         self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
 
     def _rollout_generic(self, env):
@@ -480,7 +518,9 @@ class Runner:
         """All-reduce (DP) + global-norm clip + Adam in the flat buffer (rl/rollout.py:1287-1321)."""
         opt = optimizer or self.policy_optimizer
         net, cfg = opt.net, opt.cfg
-        parallel.allreduce_sum_(net.grad)
+        red = self._reducers.get(id(net))
+        if red is not None:
+            red.finish()  # late bucket + join of the early one that left during the backward pass
         net.adam_step(lr=self._lr(cfg), beta1=cfg.adam_beta1, beta2=cfg.adam_beta2, eps=cfg.adam_epsilon,
                       max_grad_norm=args.max_grad_norm if args.grad_clip_mode == "global_norm" else 0.0,
                       grad_div=float(self.world), grad_norm_out=self._grad_norm, state=opt.state)
@@ -725,10 +765,24 @@ class Runner:
     def save_checkpoint(self, filename, step, disable_log=False, disable_replay=False, disable_env_state=False,
                         disable_optimizer=False):
         """Model under the reference's state_dict names, optimiser states, counters, env / wrapper state;
-        gzip container when --checkpoint_compression (file name + '.gz').  Returns the path written."""
+        gzip container when --checkpoint_compression (file name + '.gz').  Returns the path written.
+
+        Data parallel: replicas hold the same model, so rank 0 writes it; what differs per rank — its env columns'
+        state, its reward normaliser, its host RNG (minibatch permutations) — is gathered to rank 0 and stored as one
+        entry per rank.  Every rank must call this (it is a collective when world > 1)."""
         from . import checkpoint
-        data = {"step": step, "ep_count": self.ep_count, "batch_counter": self.batch_counter,
-                "model_state_dict": dict(self.model.state_dict()), "sample_calls": self._sample_calls}
+        local = {"np_random": np.random.get_state(), "ep_count": self.ep_count}
+        if not disable_env_state and self.vec_env is not None:
+            local["env_state"] = checkpoint.save_env_state(self.vec_env)
+        per_rank = [local]
+        if self.world > 1:
+            per_rank = [None] * self.world if self.rank == 0 else None
+            torch.distributed.gather_object(checkpoint.to_plain(local), per_rank, dst=0)
+        if self.rank != 0:
+            return None
+        data = {"step": step, "ep_count": self.ep_count, "batch_counter": self.batch_counter, "world": self.world,
+                "model_state_dict": dict(self.model.state_dict()), "sample_calls": self._sample_calls,
+                "rank_state": per_rank}
         if not disable_optimizer:
             data["policy_optimizer_state_dict"] = self.policy_optimizer.state_dict()
             if self.dual:
@@ -736,12 +790,11 @@ class Runner:
                 data["distil_optimizer_state_dict"] = self.distil_optimizer.state_dict()
         if self.model.obs_norm is not None:
             data["obs_rms"] = self.model.obs_norm.state_dict()  # rl/rollout.py:438-439
-        if not disable_env_state and self.vec_env is not None:
-            data["env_state"] = checkpoint.save_env_state(self.vec_env)
         return checkpoint.save(data, filename, bool(args.checkpoint_compression))
 
     def load_checkpoint(self, checkpoint_path):
-        """Restores model, optimisers, counters and env state; returns the env step (rl/rollout.py:472-517)."""
+        """Restores model, optimisers, counters and this rank's env / RNG state; returns the env step
+        (rl/rollout.py:472-517).  Every rank reads the file itself."""
         from . import checkpoint
         cp = checkpoint.load(checkpoint_path)
         self.model.load_state_dict(cp["model_state_dict"])
@@ -756,6 +809,19 @@ class Runner:
         self.ep_count = cp.get("ep_count", 0)
         self.batch_counter = cp.get("batch_counter", 0)
         self._sample_calls = cp.get("sample_calls", 0)
-        if cp.get("env_state") and self.vec_env is not None:
-            checkpoint.restore_env_state(self.vec_env, cp["env_state"])
+        ranks = cp.get("rank_state") or []
+        if len(ranks) == self.world:
+            mine = ranks[self.rank]
+            if mine.get("np_random") is not None:
+                np.random.set_state(mine["np_random"])
+            self.ep_count = mine.get("ep_count", self.ep_count)
+            if mine.get("env_state") and self.vec_env is not None:
+                checkpoint.restore_env_state(self.vec_env, mine["env_state"])
+                if hasattr(self.vec_env, "parts"):
+                    self.obs = np.concatenate([p.obs for p in self.vec_env.parts])
+                elif hasattr(self.vec_env, "obs"):
+                    self.obs = self.vec_env.obs
+        elif ranks:
+            self.log.warn(f"checkpoint was written by {len(ranks)} rank(s), this run has {self.world}: model and "
+                          "optimiser restored, env / RNG state not")
         return self.step

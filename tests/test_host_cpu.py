@@ -191,3 +191,69 @@ def test_annealing_follows_the_reference_schedule():
     r.step = 2.5e6
     assert abs(anneal(2.0, "linear") - 1.0) < 1e-12
     args.setup([])
+
+
+DESYNC_WORKER = r'''
+import os, sys, types
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from ppo_amd import envs, parallel, ppo
+
+
+def main():
+    from ppo_amd.config import args
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args.setup(["--agents=4", "--env_type=classic", "--env_name=CartPole", "--env_reward_normalization=rms",
+                "--seed=5", "--workers=2"])
+    np.random.seed(11 + 97 * rank)          # ranks draw DIFFERENT warm-up lengths
+    vec = envs.create_envs_classic(rank=rank, world=world)
+    calls = [0]
+    from ppo_amd import wrappers
+    norm = wrappers.get_wrapper(vec, wrappers.VecNormalizeRewardWrapper)
+    inner = norm.moments_sync
+    assert inner is not None, "data-parallel reward normalisation must reduce its moments over ranks"
+    def counted(m):
+        calls[0] += 1
+        return inner(m)
+    norm.moments_sync = counted
+    runner = types.SimpleNamespace(A=4, world=world, n_actions=2, vec_env=vec, obs=vec.reset(), device="cpu",
+                                   model=types.SimpleNamespace(obs_norm=None))
+    ppo.desync_envs(runner, 1, 9)
+    got = [None] * world
+    dist.all_gather_object(got, calls[0])
+    assert got[0] == got[1] == 9, got       # every rank issued the same number of collectives: max_duration
+    # and the collective that follows pairs up (a mismatch would hang or mix a moments reduce into it)
+    g = torch.full((1000,), float(rank + 1)); parallel.allreduce_sum_(g)
+    assert torch.equal(g, torch.full((1000,), 3.0))
+    # both ranks hold the same reward statistics, fed by all 8 envs
+    stats = [None] * world
+    dist.all_gather_object(stats, (float(norm.ret_rms.mean), float(norm.ret_rms.var), float(norm.ret_rms.count)))
+    assert stats[0] == stats[1], stats
+    vec.close()
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+
+
+if __name__ == "__main__":  # the env pool spawns workers, which re-import this file
+    main()
+'''
+
+
+def test_desync_envs_issues_the_same_collectives_on_every_rank(hip_lib, tmp_path):
+    """ADVICE r1: with gym-API envs and rms reward normalisation every env step all-reduces three moments; the
+    warm-up length is drawn per rank, so data-parallel runs must not let it set the loop length."""
+    script = tmp_path / "desync_worker.py"
+    script.write_text(DESYNC_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+        assert "ok" in o

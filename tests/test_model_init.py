@@ -10,13 +10,21 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from ppo_amd.models import ImpalaSpec, init_impala_parameters
 
 
-def test_initial_parameters_match_reference_bitwise(golden_dir):
-    meta = json.load(open(os.path.join(golden_dir, "model_golden.json")))
+def _metas(golden_dir):
+    shapes = json.load(open(os.path.join(golden_dir, "shapes_golden.json")))
+    return {"c2": json.load(open(os.path.join(golden_dir, "model_golden.json"))), "c3": shapes["c3"], "c4": shapes["c4"]}
+
+
+@pytest.mark.parametrize("tag,n_params", [("c2", 1092579), ("c3", 630126), ("c4", 1091549)])
+def test_initial_parameters_match_reference_bitwise(golden_dir, tag, n_params):
+    """c2: 4x84x84 / 6 actions (Pong), c3: 3x64x64 / 15 actions (procgen), c4: 4x84x84 / 4 actions (Breakout)."""
+    meta = _metas(golden_dir)[tag]
     torch.manual_seed(meta["seed"])
     spec = ImpalaSpec(tuple(meta["input_dims"]), hidden_units=meta["hidden_units"])
     init = init_impala_parameters(spec, meta["n_actions"], 1, meta["head_scale"], meta["head_bias"])
@@ -27,7 +35,7 @@ def test_initial_parameters_match_reference_bitwise(golden_dir):
         assert list(a.shape) == info["shape"], name
         assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == info["sha256"], name
         total += a.size
-    assert total == 1092579  # SURVEY.md §8a R9 [probed] parameter count at 6 actions
+    assert total == n_params  # c2: SURVEY.md §8a R9 [probed] parameter count at 6 actions
 
 
 def test_geometry():

@@ -41,6 +41,42 @@ def make_model(log):
         norm_eps=args.observation_normalization_epsilon)
 
 
+def get_previous_experiment_guid(experiment_path, run_name):
+    """Folder "<run_name> [<guid8>]" of an earlier run of this experiment, if any (train.py:11-19)."""
+    if not os.path.exists(experiment_path):
+        return None
+    for f in sorted(os.listdir(experiment_path)):
+        if f[:-(8 + 3)] == run_name and f.endswith("]"):
+            return f[-(8 + 1):-1]
+    return None
+
+
+def resolve_log_folder(rank=0, world=1):
+    """args.log_folder = "<output_folder>/<experiment_name>/<run_name> [<guid8>]" (train.py:142-154, 187): with
+    --restore=auto|always an earlier run's folder is reused, so its checkpoints are found.  Rank 0 decides and
+    every rank uses its answer."""
+    import uuid
+    if args.log_folder is None:
+        guid = None
+        if rank == 0:
+            if args.restore in ("always", "auto"):
+                guid = get_previous_experiment_guid(os.path.join(args.output_folder, args.experiment_name), args.run_name)
+                if guid is None and args.restore == "always":
+                    raise SystemExit(f"Could not restore experiment {args.experiment_name}:{args.run_name}. "
+                                     "Previous run not found.")
+            guid = guid or uuid.uuid4().hex[-8:]
+        if world > 1:
+            box = [guid]
+            torch.distributed.broadcast_object_list(box, src=0)
+            guid = box[0]
+        args.log_folder = "{} [{}]".format(os.path.join(args.output_folder, args.experiment_name, args.run_name), guid)
+    if rank == 0:
+        os.makedirs(args.log_folder, exist_ok=True)
+    if world > 1:
+        torch.distributed.barrier()
+    return args.log_folder
+
+
 def main():
     args.setup()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,10 +94,11 @@ def main():
     if args.seed >= 0:  # train.py:157-163
         torch.manual_seed(args.seed)
         np.random.seed(args.seed + int(os.environ.get("RANK", "0")))
-    os.makedirs(args.log_folder, exist_ok=True)
+    resolve_log_folder(int(os.environ.get("RANK", "0")), world)
+    log.info("Logging to folder " + args.log_folder)
     model = make_model(log)
     try:
-        ppo.train(model, log)
+        return ppo.train(model, log)
     finally:
         if world > 1:
             torch.distributed.destroy_process_group()
