@@ -9,37 +9,45 @@ GAE/lambda-return scan, and 2 policy epochs of 256-sample minibatches (forward, 
 global-norm clip, Adam) through the hand-written HIP IMPALA network.  value = env-steps/s summed over
 ranks (the reference's IPS, rl/ppo.py:354-365).  One process per GPU; for N > 1 the envs are sharded
 (weak scaling: 256 envs per rank, global minibatch 256*N so the optimiser-step count is unchanged)
-and the only collectives are the RCCL gradient all-reduce per optimiser step and the advantage
-moments per batch.
+and the collectives are the RCCL gradient all-reduce per optimiser step (two buckets, the large one
+overlapped with the convolution backward) and the advantage moments per batch.
+
+Launch forms: `python bench.py --gpus N` starts its own N rank processes (children, started before this
+process touches the GPU) and relays rank 0's JSON line; under `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N` (WORLD_SIZE already set) it is one of the ranks.  `--gpus` that
+disagrees with WORLD_SIZE, or asks for more GPUs than the node has, is an error, never a silent N=1.
 
 Also reported on the same JSON line:
-  roofline      the kernel with the largest share of the step (a conv weight-gradient launch), timed
-                live with HIP events on the launch stream during the timed region, against the fp32
-                MFMA peak;
-  gae_scan      the fused GAE scan at the bandwidth-regime size (N=256, A=2^20) against HBM peak, and
-                its latency at the config size;
-  cpu_baseline  the same PPO iteration through oracle/model_torch.py (plain torch CPU operators — what
-                the reference runs with --device=cpu) on a bounded sample, extrapolated to env-steps/s.
+  roofline            the kernel with the largest share of the step's GPU time (the chained LDS-resident
+                      stack launch of the training forward), timed live with HIP events on its launch
+                      stream during the timed region, against the fp32 MFMA peak;
+  roofline_by_kernel  the time-weighted picture: every kernel class of one extra (untimed) iteration of the
+                      same run, bracketed by HIP events on its launch stream — share of GPU kernel time,
+                      achieved TFLOP/s or GB/s from the algorithmic FLOPs / bytes, fraction of the peak that
+                      bounds it;
+  gae_scan            the fused GAE scan at the bandwidth-regime size (N=256, A=2^20) against HBM peak, and
+                      its latency at the config size;
+  cpu_baseline        the same PPO iteration through oracle/model_torch.py (plain torch CPU operators — what
+                      the reference runs with --device=cpu) on a bounded sample (one 256-observation rollout
+                      forward, one 256-sample minibatch), extrapolated to env-steps/s.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_* dense peak (MI355X_MICROARCH.md, Matrix cores)
-PROBE_TRAFFIC_BYTES = int((2 * 11295 + 15009) * 1024)  # conv3x3_kernel<32,32,21,21,IN_RELU> forward, batch 256
-STACK_CHAIN_TRAFFIC_BYTES = int((2 * 8625.0 + 76879.8) * 1024)  # stack_full_kernel chained training forward, batch 256
-STACK_TAIL_TRAFFIC_BYTES = int((2 * 7826.4 + 60447.7) * 1024)  # stack_tail_kernel<32,21,21> training forward, batch 256
 SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write adv4+ret4 (SURVEY.md §8d)
 FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84 (SURVEY.md §8d)
+# HBM bytes per launch of the roofline kernel from rocprofv3 --pmc passes over THIS command (tools/pmc_bench.sh
+# -> profiles/<tag>_bench_hbm_traffic.json); absent file => traffic null
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_bench_hbm_traffic.json")
 
 
 def parse():
@@ -52,33 +60,81 @@ def parse():
     p.add_argument("--scan-envs", type=int, default=1 << 20, help="A of the bandwidth-regime scan")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-scan", action="store_true")
-    p.add_argument("--scan-only", action="store_true",
-                   help="only the gae_scan section (used for the rocprofv3 --pmc passes: counter collection "
-                        "around the full PPO iteration segfaults inside rocprofv3 on this pool)")
+    p.add_argument("--no-kernel-table", action="store_true", help="skip the extra iteration behind roofline_by_kernel")
+    p.add_argument("--scan-only", action="store_true", help="only the gae_scan section (rocprofv3 --pmc passes of the scan)")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL)")
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="start the ranks, form the process group, all-reduce one number, print who was seen; no GPU work "
+                        "(the CPU test of the launcher uses it with --backend gloo)")
     return p.parse_args()
 
 
-def init_dist():
+# ----------------------------------------------------------------------------- rank launcher
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start N fresh rank processes and relay rank 0's stdout.
+    Nothing here initialises the GPU (torch.cuda.device_count() does not, on this image), so the children are
+    ordinary processes of an untouched parent — never a re-exec of a process that holds the device."""
+    n = a.gpus
+    if not a.rendezvous_only:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to report a "
+                             f"{n}-GPU number from fewer devices")
+    import socket
+    with socket.socket() as s:  # a free rendezvous port unless the caller fixed one
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+    return 0
+
+
+def init_dist(a):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch {a.gpus} ranks "
+                         f"(`python bench.py --gpus {a.gpus}` does it itself)")
+    if a.rendezvous_only:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group(a.backend, rank=rank, world_size=world)
+        return world, rank, local
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        kw = {"device_id": torch.device("cuda", local)} if a.backend == "nccl" else {}
+        torch.distributed.init_process_group(a.backend, rank=rank, world_size=world, **kw)
     return world, rank, local
 
 
 def barrier(world):
+    import torch
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(x, world):
+    import torch
     if world == 1:
         return x
     t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -86,7 +142,7 @@ def max_over_ranks(x, world):
     return float(t.item())
 
 
-# ----------------------------------------------------------------------------- live kernel probe
+# ----------------------------------------------------------------------------- live kernel probes
 class CallProbe:
     """Wraps DualHeadNet._call so that every launch of one C-ABI entry point with one geometry is
     bracketed by HIP events on the launch stream (torch's current stream)."""
@@ -100,6 +156,7 @@ class CallProbe:
         net._call = self._call
 
     def _call(self, fn_name, *a):
+        import torch
         if self.enabled and fn_name in self.fn_name and self.match(fn_name, a):
             self.seen = fn_name
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -110,12 +167,154 @@ class CallProbe:
         else:
             self._orig(fn_name, *a)
 
+    def remove(self):
+        self.net._call = self._orig
+
     def avg_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
 
 
+def _conv(n, cin, cout, h, w):
+    return 2.0 * 9 * cin * cout * h * w * n
+
+
+def _half(x):
+    return (x + 1) // 2
+
+
+# entry point -> (label, algorithmic FLOPs, algorithmic HBM bytes) of one launch, from the C-ABI arguments
+# (include/ppo_amd.h).  FLOPs bound the MFMA kernels, bytes the streaming ones; neither => latency-bound helper.
+def describe_call(fn, a):
+    f32 = 4
+    if fn in ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32"):
+        n, ci, co, h, w = a[6:11]
+        return f"conv3x3 fwd {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
+    if fn in ("ppo_conv3x3_pool_forward_f32", "ppo_conv3x3_pool_forward_packed_f32"):
+        n, ci, co, h, w = a[6:11]
+        return f"conv3x3+maxpool fwd {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
+    if fn in ("ppo_conv3x3_backward_data_f32", "ppo_conv3x3_backward_data_packed_f32"):
+        n, ci, co, h, w = a[5:10]
+        return f"conv3x3 bwd-data {co}->{ci} {h}x{w}", _conv(n, ci, co, h, w), None
+    if fn == "ppo_conv3x3_backward_weight_slabs_f32":
+        n, ci, co, h, w = a[5:10]
+        return f"conv3x3 wgrad {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
+    if fn == "ppo_conv3x3_backward_weight_slabs_pooled_f32":
+        n, ci, co, h, w = a[6:11]
+        return f"conv3x3 wgrad+pool-bwd {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
+    if fn == "ppo_conv3x3_backward_weight_slabs_batch_f32":
+        k, n, ci, co, h, w = a[5:11]
+        return f"conv3x3 wgrad x{k} {ci}->{co} {h}x{w}", k * _conv(n, ci, co, h, w), None
+    if fn == "ppo_conv3x3_backward_weight_f32":
+        n, ci, co, h, w = a[7:12]
+        return f"conv3x3 wgrad {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
+    if fn == "ppo_impala_stack_tail_forward_f32":
+        n, c, h, w = a[7:11]
+        return f"stack blocks fwd (4 conv) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
+    if fn == "ppo_impala_stack_tail_backward_f32":
+        n, c, h, w = a[7:11]
+        return f"stack blocks bwd-data (4 conv) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
+    if fn == "ppo_impala_stack_full_forward_f32":
+        n, c, h, w = a[9:13]
+        return (f"whole stack fwd (5 conv + pool) {c}ch {h}x{w}",
+                _conv(n, c, c, h, w) + 4 * _conv(n, c, c, _half(h), _half(w)), None)
+    if fn == "ppo_impala_stack_chain_forward_f32":
+        n, c, h, w = a[15:19]
+        return (f"chained stacks fwd (9 conv + pool) {c}ch {h}x{w}",
+                5 * _conv(n, c, c, h, w) + 4 * _conv(n, c, c, _half(h), _half(w)), None)
+    if fn == "ppo_impala_stack_full_backward_f32":
+        n, c, h, w = a[10:14]
+        return (f"whole stack bwd-data (5 conv + pool) {c}ch {h}x{w}",
+                _conv(n, c, c, h, w) + 4 * _conv(n, c, c, _half(h), _half(w)), None)
+    if fn in ("ppo_impala_stack16_forward_f32", "ppo_impala_stack16_backward_f32"):
+        n, c, h, w = a[-4:]
+        kind = "fwd" if fn.endswith("forward_f32") else "bwd-data"
+        return f"stack blocks {kind} (4 conv, sliding window) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
+    if fn == "ppo_gemm_f32":
+        M, N, K = a[12:15]
+        return f"gemm {M}x{N}x{K}", 2.0 * M * N * K, None
+    if fn == "ppo_gather_rows":
+        return "gather observation rows", None, 2.0 * a[1] * a[4]
+    if fn == "ppo_adam_step_f32":
+        return "grad-norm + clip + Adam", None, 28.0 * a[4]
+    if fn == "ppo_maxpool3x3s2_forward_f32":
+        n, c, h, w = a[3:7]
+        return f"maxpool fwd {c}ch {h}x{w}", None, n * c * (f32 * h * w + 5.0 * _half(h) * _half(w))
+    if fn == "ppo_maxpool3x3s2_backward_f32":
+        n, c, h, w = a[3:7]
+        return f"maxpool bwd {c}ch {h}x{w}", None, n * c * (f32 * h * w + 5.0 * _half(h) * _half(w))
+    if fn == "ppo_gae_scan_f32":
+        return "gae scan", None, float(SCAN_BYTES_PER_ELEM) * a[7] * a[8]
+    short = {"ppo_conv3x3_wgrad_reduce_f32": "wgrad slab reduction", "ppo_conv3x3_pack_weights_f32": "weight pack",
+             "ppo_policy_act_f32": "policy sampling", "ppo_ppo_loss_f32": "PPO loss", "ppo_colsum_f32": "column sums",
+             "ppo_moments_f64": "advantage moments", "ppo_normalize_f32": "advantage normalise"}
+    return short.get(fn, fn), None, None
+
+
+class KernelTable:
+    """Every C-ABI launch of one (untimed) iteration bracketed by HIP events on its launch stream, grouped by
+    kernel class.  Durations of kernels that share the chip with another stream's kernels (backward-data next to
+    the weight gradients; the two rollout groups) include that sharing, as in a rocprofv3 trace."""
+
+    def __init__(self, objs):
+        self.rows = {}
+        self._undo = []
+        for o in objs:
+            orig = o._call
+            o._call = self._wrap(orig)
+            self._undo.append((o, orig))
+
+    def _wrap(self, orig):
+        import torch
+
+        def call(fn_name, *a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(fn_name, *a)
+            e1.record()
+            label, flops, nbytes = describe_call(fn_name, a)
+            row = self.rows.setdefault(label, {"events": [], "flops": 0.0, "bytes": 0.0})
+            row["events"].append((e0, e1))
+            row["flops"] += flops or 0.0
+            row["bytes"] += nbytes or 0.0
+        return call
+
+    def remove(self):
+        for o, orig in self._undo:
+            o._call = orig
+
+    def table(self, top=24):
+        out, total = [], 0.0
+        for label, row in self.rows.items():
+            ms = sum(a.elapsed_time(b) for a, b in row["events"])
+            total += ms
+            out.append((ms, label, row))
+        out.sort(reverse=True)
+        rows = []
+        for ms, label, row in out[:top]:
+            r = {"kernel": label, "share": round(ms / total, 4), "launches": len(row["events"]),
+                 "avg_us": round(1e3 * ms / len(row["events"]), 2)}
+            if row["flops"]:
+                r.update(bound="mfma", achieved=round(row["flops"] / (ms * 1e-3) / 1e12, 2), unit="TFLOP/s")
+                r["frac"] = round(r["achieved"] / MFMA_F32_PEAK_TFLOPS, 4)
+            elif row["bytes"]:
+                r.update(bound="hbm", achieved=round(row["bytes"] / (ms * 1e-3) / 1e9, 1), unit="GB/s")
+                r["frac"] = round(r["achieved"] / HBM_PEAK_GBPS, 4)
+            else:
+                r.update(bound="latency")
+            rows.append(r)
+        mfma_ms = sum(ms for ms, _l, row in out if row["flops"])
+        mfma_flops = sum(row["flops"] for _ms, _l, row in out)
+        return {"kernel_ms_total": round(total, 2), "rows": rows,
+                "mfma_kernels": {"share": round(mfma_ms / total, 4),
+                                 "time_weighted_frac_of_peak": round(mfma_flops / (mfma_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+                "note": "one extra iteration of the same run; per-launch HIP events on the launch stream; kernels that "
+                        "overlap another stream's kernels carry that sharing in their duration"}
+
+
 # ----------------------------------------------------------------------------- GAE scan section
 def bench_scan(lib, N, A_big, A_cfg):
+    import numpy as np
+    import torch
     from ppo_amd import _lib
     out = {}
     for tag, A, reps in (("bandwidth", A_big, 10), ("config", A_cfg, 50)):
@@ -162,15 +361,17 @@ def bench_scan(lib, N, A_big, A_cfg):
 
 # ----------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(N, A, epochs, mb):
-    """The PPO iteration on the host through plain torch CPU ops (oracle/model_torch.py), bounded:
-    time one rollout forward of `fb` observations and one train minibatch of `tb` samples, then
-    extrapolate to a full iteration of N*A env steps."""
+    """The PPO iteration on the host through plain torch CPU ops (oracle/model_torch.py), bounded: one rollout
+    forward of `A` observations and one train minibatch of `mb` samples (the GPU workload's own batch sizes) are
+    timed, then extrapolated to a full iteration of N*A env steps."""
+    import numpy as np
+    import torch
     from oracle import model_torch as R, returns as O
     from ppo_amd.models import ImpalaSpec, init_impala_parameters
     threads = torch.get_num_threads()
     torch.manual_seed(1)
     init = init_impala_parameters(ImpalaSpec((4, 84, 84)), 6, 1, 0.1, True)
-    fb, tb = 64, 64
+    fb, tb = A, mb
     rng = np.random.default_rng(0)
     xf = torch.from_numpy(rng.integers(0, 256, (fb, 4, 84, 84), dtype=np.uint8))
     xt = torch.from_numpy(rng.integers(0, 256, (tb, 4, 84, 84), dtype=np.uint8))
@@ -194,7 +395,7 @@ def cpu_baseline(N, A, epochs, mb):
     for name, fn in (("fwd", fwd), ("train", train)):
         fn()
         t0, reps = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 6.0 and reps < 20:
+        while reps < 1 or (time.perf_counter() - t0 < 6.0 and reps < 20):
             fn()
             reps += 1
         times[name] = (time.perf_counter() - t0) / reps
@@ -215,14 +416,30 @@ def cpu_baseline(N, A, epochs, mb):
 # ----------------------------------------------------------------------------- main
 def main():
     a = parse()
-    world, rank, local = init_dist()
-    from ppo_amd import _lib, envs, logger, models, rollout
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
+    world, rank, local = init_dist(a)
+    import numpy as np
+    import torch
+    if a.rendezvous_only:
+        t = torch.ones(1)
+        if world > 1:
+            torch.distributed.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": a.gpus, "ranks_seen": int(t.item()),
+                              "backend": torch.distributed.get_backend() if world > 1 else "none"}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return 0
+    from ppo_amd import _lib, envs, logger, models, parallel, rollout
     from ppo_amd.config import args
     lib = _lib.load()
     N, A = a.n_steps, a.agents
     if a.scan_only:
         print(json.dumps({"gae_scan": bench_scan(lib, N, a.scan_envs, A)}), flush=True)
-        return
+        return 0
     mb = 256
     args.setup([f"--agents={A}", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala",
                 "--env_type=synthetic", "--env_embed_time=False", "--seed=1", f"--device=cuda:{local}",
@@ -237,11 +454,15 @@ def main():
     runner = rollout.Runner(model, logger.Logger(quiet=True))
     runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
     runner.reset()
-    # dominant kernel of the step (profiles/r01e: largest total time): the 32->32 21x21 forward convolution of the
-    # residual blocks, conv3x3_kernel<32,32,21,21,..,IN_RELU>; the train-minibatch launches (n == mb) are timed
-    # of the residual-block convolutions of the 21x21 stack: one fused launch per training forward
-    # (stack_tail_kernel<32,21,21>: 4 convolutions, image resident in LDS) or, with PPO_AMD_FUSE_STACK_TAIL=0, the
-    # individual conv3x3_kernel<32,32,21,21,IN_RELU> launches.  Only minibatch-sized training launches are timed.
+    if os.environ.get("PPO_AMD_DUMP_MAPS"):
+        # diagnostics for crashes under a profiler: the load addresses that turn a raw stack trace into library + offset
+        with open(os.environ["PPO_AMD_DUMP_MAPS"], "w") as f:
+            f.write(open("/proc/self/maps").read())
+
+    # The roofline probe: the kernel with the largest share of GPU time in profiles/ — the training forward's chained
+    # LDS-resident launch (residual blocks of the 21x21 stack + the whole 11x11 stack); with the fused paths switched
+    # off (PPO_AMD_FUSE_STACK_TAIL / _CHAIN = 0) it falls back to the stack-tail launch or the single 32->32 21x21
+    # forward convolution.  Only minibatch-sized training launches are timed (n == mb).
     def probe_match(fn_name, c):
         if fn_name == "ppo_impala_stack_chain_forward_f32":  # (in, pre_w, pre_b, pre_a0..pre_q1, w, b, pooled, argmax,
             return c[3] is not None and (c[15], c[16], c[17], c[18]) == (mb, 32, 21, 21)  # a0..q1, n, channels, h, w)
@@ -261,6 +482,9 @@ def main():
 
     for _ in range(a.warmup):
         iteration()
+    reducer = runner._reducers.get(id(runner.net))
+    if reducer is not None:
+        reducer.exposed_ms()  # drop the warm-up's marks
     barrier(world)
     probe.enabled = True
     phase = {"rollout": 0.0, "returns": 0.0, "train": 0.0}
@@ -278,13 +502,14 @@ def main():
     barrier(world)
     wall = max_over_ranks(time.perf_counter() - t0, world)
     probe.enabled = False
+    probe.remove()
     stats = runner.fetch_stats()
+    exposed_comm_ms = reducer.exposed_ms() if reducer is not None else None
 
     env_steps = world * N * A * a.steps
     if not probe.events:
         raise SystemExit("bench.py: the roofline probe saw no launch of its kernel (entry point renamed?)")
     kern_ms = probe.avg_ms()
-    fused = probe.seen == "ppo_impala_stack_tail_forward_f32"
     map_bytes = 32 * 21 * 21 * 4 * mb
     small_bytes = 32 * 11 * 11 * 4 * mb
     if probe.seen == "ppo_impala_stack_chain_forward_f32":
@@ -293,20 +518,25 @@ def main():
         # pooled 11x11 map and its uint8 argmax
         probe_flops = 5 * conv_flops + 4 * (2 * 9 * 32 * 32 * 11 * 11 * mb)
         probe_bytes = 5 * map_bytes + 5 * small_bytes + small_bytes // 4
-        probe_traffic = STACK_CHAIN_TRAFFIC_BYTES
         probe_kernel = ("stack_full_kernel<32,21,21 -> 11,11> chained training forward: residual blocks of the 21x21 stack + "
                         "the whole 11x11 stack (9 convolutions + max-pool) in one launch, maps resident in LDS "
                         "(ppo_impala_stack_chain_forward_f32, minibatch launches)")
-        probe_source = "profiles/r01l_stack_tail_hbm_traffic.md"
-    elif fused:   # reads the block input, writes a0, q0, a1, q1 for the backward pass
-        probe_flops, probe_bytes, probe_traffic = 4 * conv_flops, 5 * map_bytes, STACK_TAIL_TRAFFIC_BYTES
+        traffic_key = "stack_full_kernel"
+    elif probe.seen == "ppo_impala_stack_tail_forward_f32":   # reads the block input, writes a0, q0, a1, q1
+        probe_flops, probe_bytes = 4 * conv_flops, 5 * map_bytes
         probe_kernel = ("stack_tail_kernel<32,21,21> training forward: the 4 residual-block convolutions of the 21x21 "
                         "stack in one launch (ppo_impala_stack_tail_forward_f32, minibatch launches)")
-        probe_source = "profiles/r01l_stack_tail_hbm_traffic.md"
+        traffic_key = "stack_tail_kernel"
     else:
-        probe_flops, probe_bytes, probe_traffic = conv_flops, 2 * map_bytes, PROBE_TRAFFIC_BYTES
+        probe_flops, probe_bytes = conv_flops, 2 * map_bytes
         probe_kernel = "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)"
-        probe_source = "profiles/r01j_conv_hbm_traffic.md"
+        traffic_key = "conv3x3_kernel"
+    traffic, traffic_source = None, "no PMC pass over this command on file (tools/pmc_bench.sh)"
+    if mb == 256 and os.path.exists(TRAFFIC_FILE):
+        rec = json.load(open(TRAFFIC_FILE)).get(traffic_key)
+        if rec:
+            traffic = int(rec["hbm_bytes_per_launch"])
+            traffic_source = os.path.relpath(TRAFFIC_FILE, ROOT) + ": " + rec.get("how", "")
     tflops = probe_flops / (kern_ms * 1e-3) / 1e12
     samples_fwd = (N + 1) * A + args.policy_opt.epochs * N * A
     samples_bwd = args.policy_opt.epochs * N * A
@@ -316,6 +546,8 @@ def main():
         "value": round(env_steps / wall, 1),
         "unit": "env-steps/s",
         "n_gpus": world,
+        "ranks_seen": parallel.world_size(),
+        "backend": parallel.backend_name(),
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(wall / a.steps * 1e3, 2),
@@ -331,20 +563,35 @@ def main():
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                     # HBM bytes per launch of this kernel at this shape: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-                     # separate passes over tools/conv_tune (counter collection around the whole PPO iteration
-                     # segfaults in rocprofv3 on this pool), 2 x FETCH_SIZE + WRITE_SIZE KiB as the guide prescribes
-                     # for gfx950; algorithmic = input + output = 28.9 MB, the 8/6 halo-row re-read accounts for the rest
-                     "traffic": probe_traffic if mb == 256 else None,
-                     "traffic_source": probe_source,
+                     # HBM bytes per launch of this kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate
+                     # runs) over this same bench.py command, 2 x FETCH_SIZE + WRITE_SIZE KiB as the guide prescribes
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": probe_bytes,
                      "kernel": probe_kernel,
                      "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
                      "launches_timed": len(probe.events)},
         "phase_seconds_per_step": {k: round(v / a.steps, 4) for k, v in phase.items()},
         "model_tflops_whole_step": round(model_tflops / world, 2),
+        "model_frac_of_mfma_peak_whole_step": round(model_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
         "train_stats": {k: round(float(v), 6) for k, v in stats.items()},
     }
+    if world > 1:
+        out["grad_allreduce"] = {"buckets": 2, "exposed_ms_per_optimizer_step": None if exposed_comm_ms is None
+                                 else round(exposed_comm_ms, 4),
+                                 "note": "time the compute stream waited between 'backward queued' and 'gradients reduced'"}
+    if not a.no_kernel_table:
+        # the time-weighted picture: one more iteration of the same run with every launch bracketed (untimed; the
+        # rollout's recorded launch plans are dropped so that its launches pass through the bracket too)
+        nets = list({id(n): n for n in (model.policy_net, model.value_net)}.values())
+        for n_ in nets:
+            n_._plans.clear()
+        kt = KernelTable([runner] + nets)
+        iteration()
+        torch.cuda.synchronize()
+        kt.remove()
+        for n_ in nets:
+            n_._plans.clear()
+        out["roofline_by_kernel"] = kt.table()
     if rank == 0:
         if world == 1 and not a.no_scan:
             out["gae_scan"] = bench_scan(lib, N, a.scan_envs, A)
@@ -353,7 +600,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -257,3 +257,31 @@ def test_desync_envs_issues_the_same_collectives_on_every_rank(hip_lib, tmp_path
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
         assert "ok" in o
+
+
+def _bench(*argv, env=None, timeout=180):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` is the driver's single-command form: it must start N ranks itself (gloo dry run
+    here: rendezvous + one all-reduce, no GPU), and must never fall back to a silent N = 1."""
+    import json
+    r = _bench("--gpus", "2", "--rendezvous-only", "--backend", "gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["ranks_seen"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo"
+    # more GPUs than the node has: refused before any rank starts (this container has none)
+    r = _bench("--gpus", "2")
+    assert r.returncode != 0 and "exposes" in (r.stderr + r.stdout)
+    # a launcher that set WORLD_SIZE to something else: refused, not reported as --gpus
+    r = _bench("--gpus", "2", "--rendezvous-only", "--backend", "gloo", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    # N = 1 takes no launcher and no process group
+    r = _bench("--gpus", "1", "--rendezvous-only")
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
