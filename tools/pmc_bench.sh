@@ -7,7 +7,9 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmcb_$TAG
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-scan --no-kernel-table"
+# --n-steps 8: the same iteration with a short rollout.  rocprofv3's counter-collection interceptor segfaults once a queue has
+# carried ~16 k AQL packets (profiles/r02a_pmc_segv_analysis.md); the training kernels keep their minibatch geometry.
+ARGS="--n-steps 8 --steps 1 --warmup 1 --no-cpu-baseline --no-scan --no-kernel-table"
 rc=0
 for C in FETCH_SIZE WRITE_SIZE; do
   c=$(echo $C | tr A-Z a-z | sed 's/_size//')
