@@ -115,7 +115,17 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = (size_t)(NBUF * LDS_IN) * 4;
 };
 
-template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED, bool PACKED>
+// WIDE epilogue (maps whose channel planes and bands are whole float4s): the accumulators of a wave's tiles are
+// transposed through a wave-private LDS scratch from the MFMA layout (lane = pixel x 4 channels) to lane = 4
+// consecutive pixels of one channel, so the ReLU gate, the residual and the result travel as ONE 16-byte access per
+// lane and tile instead of four 4-byte ones.  The per-lane dword form issued 24-48 memory instructions per group and
+// wave: the CU's one memory pipeline, not the MFMA pipe, set the pace (stamps: 40 % of a backward-data item spent
+// issuing the gate / residual loads).  Same arithmetic per element, so the bits do not change.
+constexpr int kScrPitch = 20;  // floats per scratch row: 16 pixels + 4, so channel rows 4 apart are 16 banks apart
+template <int MT, int NT>
+constexpr int conv_scratch_floats() { return MT * NT * 16 * kScrPitch; }  // per wave
+
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED, bool PACKED, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     const void *__restrict__ in_, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ residual, const float *__restrict__ mask_src, float *__restrict__ out,
@@ -192,6 +202,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             const int co = n * 16 + g * 4 + r;
             bias_r[n][r] = (bias && co < COUT) ? bias[co] : 0.f;
         }
+    // WIDE: lane = (channel ch of a 16-channel tile, 4 consecutive pixels quad*4..+3)
+    const int ch = lane >> 2, quad = lane & 3;
+    float bias_c[C::NT];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) bias_c[n] = (WIDE && bias && n * 16 + ch < COUT) ? bias[n * 16 + ch] : 0.f;
+    float *scr = smem + C::NBUF * C::LDS_IN + wave * conv_scratch_floats<MT, C::NT>();  // wave-private, WIDE only
     if constexpr (DMA) {
         zero_lds<C::NBUF * C::LDS_IN, kConvThreads>(smem, tid);  // halo columns + padded channels stay zero
         __syncthreads();
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     // results of the last group a wave computed are STORED one barrier later (after the next item's
     // barrier, before its DMA request): the barrier's vmcnt(0) then only ever waits for memory
     // operations that were issued a whole item ago, never for stores it has just issued.
-    float pend[MT][C::NT][4];
+    float pend[MT][C::NT][4];  // WIDE: element e = pixel pend_off + e of channel n*16 + ch
     int pend_off[MT];
     bool pend_live[MT];
     float *pend_base = out;
@@ -243,6 +259,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
 #pragma unroll
         for (int m = 0; m < MT; ++m)
             if (pend_live[m]) {
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+                        if (n * 16 + ch < COUT)
+                            *reinterpret_cast<float4 *>(pend_base + pend_off[m] + (n * 16 + ch) * (H * W)) =
+                                make_float4(pend[m][n][0], pend[m][n][1], pend[m][n][2], pend[m][n][3]);
+                    pend_live[m] = false;
+                    continue;
+                }
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n)
 #pragma unroll
@@ -301,8 +326,25 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             float gate[MT][C::NT][4], res[MT][C::NT][4];
             const float *mask_img = mask_src ? mask_src + img_off : nullptr;
             const float *res_img = residual ? residual + img_off : nullptr;
+            int p4[MT];  // WIDE: first of this lane's 4 pixels of tile m
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
+                if constexpr (WIDE) {
+                    p4[m] = ((wave + q * kConvWaves) * MT + m) * 16 + quad * 4;
+                    live[m] = p4[m] < plim;  // plim is a multiple of 4: a quad is whole or absent
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) {
+                        const int oi = p4[m] + (n * 16 + ch) * (H * W);
+                        const bool ok = live[m] && n * 16 + ch < COUT;
+                        const float4 gv = (mask_img && ok) ? *reinterpret_cast<const float4 *>(mask_img + oi)
+                                                           : make_float4(1.f, 1.f, 1.f, 1.f);
+                        const float4 rv = (res_img && ok) ? *reinterpret_cast<const float4 *>(res_img + oi)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                        gate[m][n][0] = gv.x, gate[m][n][1] = gv.y, gate[m][n][2] = gv.z, gate[m][n][3] = gv.w;
+                        res[m][n][0] = rv.x, res[m][n][1] = rv.y, res[m][n][2] = rv.z, res[m][n][3] = rv.w;
+                    }
+                    continue;
+                }
                 live[m] = pix[q][m] < plim;
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n)
@@ -421,6 +463,35 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             // ---- epilogue: lane holds pixel (lane & 15) x channels g*4 .. g*4+3 of each tile; the values
             // are parked in registers and written by the next flush()
             pend_base = out + img_off;
+            if constexpr (WIDE) {
+                // MFMA layout -> scratch rows [channel][16 pixels]; DS operations of a wave complete in order, so the
+                // reads below see the writes of the other lanes without a barrier
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            scr[((m * C::NT + n) * 16 + g * 4 + r) * kScrPitch + l15] = acc[n][m][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    pend_live[m] = live[m];
+                    pend_off[m] = p4[m];
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) {
+                        const float4 o = *reinterpret_cast<const float4 *>(scr + ((m * C::NT + n) * 16 + ch) * kScrPitch + quad * 4);
+                        const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float val = ov[e] + bias_c[n];
+                            val = gate[m][n][e] > 0.f ? val : 0.f;
+                            pend[m][n][e] = val + res[m][n][e];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 pend_live[m] = live[m];
@@ -434,6 +505,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
                         pend[m][n][r] = val + res[m][n][r];
                     }
             }
+            }
         }
         PPO_STAMP(t_end)
         PPO_STAMP_ADD(3, t_end, t_staged)  // whole compute section of the item (all groups + epilogues)
@@ -444,16 +516,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
     flush();
 }
 
-template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED, bool PACKED>
+template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, bool TRANSPOSED, bool PACKED, bool WIDE>
 int launch_conv_impl(const void *in, const float *w, const float *bias, const float *residual,
                      const float *mask_src, float *out, int n_images, hipStream_t st)
 {
     using C = ConvCfg<CIN, COUT, H, W, TR, IN_MODE != IN_U8>;
-    auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, PACKED>;
+    auto kern = conv3x3_kernel<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, PACKED, WIDE>;
     constexpr int kConvThreads = NW * 64;
-    // the band buffers, or the padded weight image the prologue stages through the same region
+    // the band buffers (+ the WIDE epilogue's per-wave scratch), or the padded weight image the prologue stages
+    // through the same region
     constexpr size_t kWeightImage = (size_t)(TRANSPOSED ? CIN : COUT) * (((TRANSPOSED ? COUT : CIN) * 9) | 1) * 4;
-    constexpr size_t kLdsBytes = C::LDS_BYTES > kWeightImage ? C::LDS_BYTES : kWeightImage;
+    constexpr size_t kBands = C::LDS_BYTES + (WIDE ? (size_t)NW * conv_scratch_floats<MT, C::NT>() * 4 : 0);
+    constexpr size_t kLdsBytes = kBands > kWeightImage ? kBands : kWeightImage;
     static int wg_per_cu = 0;  // resident workgroups per CU (LDS- and VGPR-limited), queried once
     if (wg_per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -481,11 +555,27 @@ template <int CIN, int COUT, int H, int W, int TR, int MT, int NW, int IN_MODE, 
 int launch_conv(const void *in, const float *w, const float *bias, const float *residual, const float *mask_src,
                 float *out, int n_images, hipStream_t st)
 {
+    // the 16-byte epilogue needs whole float4s: channel planes and bands a multiple of 4 floats, 16-byte aligned tensors
+    constexpr bool kWideGeo = (H * W) % 4 == 0 && (TR * W) % 4 == 0 && IN_MODE != IN_U8;
+#ifdef PPO_TUNE_NO_WIDE
+    const bool wide = false;
+#else
+    const bool wide = kWideGeo && aligned(out, 16) && (!residual || aligned(residual, 16)) && (!mask_src || aligned(mask_src, 16));
+#endif
+    if constexpr (kWideGeo) {
+        if (wide) {
+            if (t_weights_packed)
+                return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, true, true>(in, w, bias, residual,
+                                                                                                     mask_src, out, n_images, st);
+            return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, false, true>(in, w, bias, residual,
+                                                                                                  mask_src, out, n_images, st);
+        }
+    }
     if (t_weights_packed)
-        return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, true>(in, w, bias, residual, mask_src,
-                                                                                         out, n_images, st);
-    return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, false>(in, w, bias, residual, mask_src, out,
-                                                                                      n_images, st);
+        return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, true, false>(in, w, bias, residual, mask_src,
+                                                                                                out, n_images, st);
+    return launch_conv_impl<CIN, COUT, H, W, TR, MT, NW, IN_MODE, TRANSPOSED, false, false>(in, w, bias, residual, mask_src,
+                                                                                             out, n_images, st);
 }
 
 // Supported layer geometries: Atari 84x84 (rl/atari.py) and Procgen 64x64 (rl/procgen.py)

@@ -10,8 +10,18 @@
 // row per v_mfma_f32_16x16x4_f32.
 //
 // A 512-thread workgroup (8 waves) walks (image, row band) items.  Both bands sit in LDS, planar, plane
-// stride = 2 (mod 32) banks so that 16 channels x 2 adjacent pixels are conflict-free; two extra planes
-// hold 1.0 (the bias column) and 0.0 (padding columns), so the K loop has no selects or branches
+// stride = 2 (mod 32) banks so that 16 channels x 2 adjacent pixels are conflict-free; an extra plane holds
+// 0.0 (padding columns) and, where the bias column fits into the padding of the last N tile anyway (4 input
+// channels: 37 of 48 columns), another holds 1.0, so the K loop has no selects or branches.  Where 9*CINP is a
+// multiple of 16 (16 / 32 input channels) a ones column would cost a whole extra N tile (10 instead of 9, 19
+// instead of 18 tiles: 5-11 % more MFMAs); there db is the running sum of the A operand each lane reads anyway.
+// Float inputs (every layer but the uint8 observation convolution) use the RUN layout of the forward kernels: a
+// channel's band rows sit back to back with the image's own row stride and NO halo columns, in the dy band too, so a
+// plane is one contiguous run that 16-byte LDS-DMA requests move (the 4-byte request per row of the halo-column layout
+// was what bounded these kernels: 256 requests per 42x42 item, the K loop waiting at the item barrier for them; cutting
+// 11 % of the MFMAs changed nothing).  K runs over the flat pixel index 4 at a time with no per-row padding (21 -> 24
+// columns cost 14 % of the K steps); the x-1 / x+1 taps of a pixel in the first / last column read the neighbouring
+// row's pixel and are zeroed by a select that exists only in the (compile-time known) steps that touch a row end
 // (the first version chose 1/0/x per lane and skipped tiles per wave: hipcc turned that into exec-masked
 // branches and accumulator copies, 30 VALU per MFMA).  wave % 4 owns a fixed set of N tiles (the wave
 // count per tile set is a compile-time property of the code path the wave takes), wave / 4 splits the
@@ -35,36 +45,54 @@ constexpr int pad_mod32(int v, int target) { return v + ((target - v % 32) + 32)
 // Double-buffered staging pays where the bands arrive by LDS-DMA and a workgroup sees several items; uint8
 // observations are staged through registers (the copy cannot overlap the K loop) and the 11x11 / 8x8 layers
 // are one item per workgroup (measured: 62 vs 76 us and 20.9 vs 21.8 us single-buffered).
+#ifndef PPO_TUNE_WGRAD_NBUF
+#define PPO_TUNE_WGRAD_NBUF 2
+#endif
+#ifndef PPO_TUNE_WGRAD_PERCU
+#define PPO_TUNE_WGRAD_PERCU 2
+#endif
 template <int IN_MODE, int NBANDS>
-constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : 2; }
+constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : PPO_TUNE_WGRAD_NBUF; }
+// contiguous-run band layout (16-byte LDS-DMA) wherever both bands arrive by DMA
+template <int IN_MODE, bool DY_POOLED>
+constexpr bool wgrad_run() { return IN_MODE != IN_U8 && !DY_POOLED; }
 constexpr int kWgradWaves = 8;
 
-template <int CIN, int COUT, int H, int W, int TR, int NBUF_>
+template <int CIN, int COUT, int H, int W, int TR, int NBUF_, bool RUN_>
 struct WgradCfg {
     static constexpr int CINP = (CIN + 3) / 4 * 4;
     static constexpr int MTC = COUT / 16;
-    static constexpr int NJ = 9 * CINP + 1;  // + the ones column (bias gradient)
+    // bias gradient: a ones column of B where it is free (the last N tile has a spare column), else lane sums of A
+    static constexpr bool BIAS_IN_TILE = (9 * CINP) % 16 != 0;
+    static constexpr int NJ = 9 * CINP + (BIAS_IN_TILE ? 1 : 0);
     static constexpr int NTT = (NJ + 15) / 16;
-    static constexpr int JP = NTT * 16;
+    static constexpr int JP = ((9 * CINP + 1) + 15) / 16 * 16;  // slab row: the N tiles, then (or inside them) column 9*CINP = db
     // The 8 waves are WT tile owners x KG K-split groups.  WT is chosen so the N tiles divide (almost) evenly:
     // 3 tiles (4 input channels) -> every wave owns all 3 and takes an eighth of K; 10 tiles (16 channels) ->
     // 2 owners x 5 tiles, K in quarters; 19 tiles (32 channels) -> 4 owners x 5/5/5/4, K in halves.  (With a
     // fixed 4 x 2 split the 10-tile layers ran 3/3/2/2 tiles per owner: a third of the K loop spent waiting at
     // the item barrier.)
-    static constexpr int WT = NTT <= 4 ? 1 : (NTT <= 12 ? 2 : 4);
+    // 9 tiles (16 channels, db by lane sums) -> one owner, K in eighths; 18 tiles (32 channels) -> 2 owners x 9, K in quarters.
+    static constexpr int WT = (NTT <= 4 || NTT == 9) ? 1 : ((NTT <= 12 || NTT == 18) ? 2 : 4);
     static constexpr int KG = kWgradWaves / WT;
     static constexpr int NTW_MAX = (NTT + WT - 1) / WT;  // tiles of owners with index < REM
     static constexpr int REM = NTT % WT == 0 ? WT : NTT % WT;
-    static constexpr int PWD = (W + 3) / 4 * 4;
-    static constexpr int PWX = PWD + 2;
+    static constexpr int WIDTH = W;
+    static constexpr bool RUN = RUN_;                   // contiguous rows, no halo columns, K over the flat band index
+    static_assert(RUN || W % 4 == 0, "the halo-column layout steps whole rows 4 pixels at a time");
+    static constexpr int G = 4;                         // RUN: guard floats in front of the rows of an x plane
+    static constexpr int PWD = W;                       // dy row pitch
+    static constexpr int PWX = RUN ? W : W + 2;         // x row pitch (halo-column layout: pixel column c at c + 1)
     static constexpr int ROWS = TR + 2;
-    static constexpr int XPLANE = pad_mod32(ROWS * PWX, 2);
-    static constexpr int DPLANE = pad_mod32(TR * PWD, 2);
     static constexpr int NBANDS = (H + TR - 1) / TR;
-    static constexpr int STEPS = TR * (PWD / 4);
-    static constexpr int LDS_X = (CINP + 2) * XPLANE;  // + ones plane + zeros plane
+    static constexpr int STEPS = RUN ? (TR * W + 3) / 4 : TR * (W / 4);
+    // RUN: step s reads dy[4s .. 4s+3] and x[4s + G - 1 + ky*W + kx + 0..3]
+    static constexpr int XRUN = 4 * STEPS + 2 * W + 2 * G > ROWS * W + 2 * G ? 4 * STEPS + 2 * W + 2 * G : ROWS * W + 2 * G;
+    static constexpr int XPLANE = pad_mod32(RUN ? XRUN : ROWS * PWX, 2);
+    static constexpr int DPLANE = pad_mod32(RUN ? 4 * STEPS : TR * PWD, 2);
+    static constexpr int LDS_X = (CINP + 2) * XPLANE;  // + ones plane (BIAS_IN_TILE) + zeros plane
     static constexpr int LDS_D = COUT * DPLANE;
-    static constexpr int LDS_RED = (KG - 1) * COUT * JP;  // cross-K-group reduction images (reuse the staging space)
+    static constexpr int LDS_RED = COUT * JP;  // ONE cross-K-group reduction image (reuses the staging space): groups fold in turn
     static constexpr int NBUF = NBUF_;              // staging buffers: 2 = the next item's bands are in flight
     static constexpr int LDS_BUF = LDS_X + LDS_D;   //   (LDS-DMA) while this item's K loop runs, one barrier per item
     static constexpr int LDS_WORDS = NBUF * LDS_BUF > LDS_RED ? NBUF * LDS_BUF : LDS_RED;
@@ -78,10 +106,11 @@ struct WgradCfg {
 // from a runtime range exposed the whole LDS latency on every step: 58 % of the MFMA rate in its K loop).
 template <class C, int NTW, bool RELU, int KGI>
 __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, const float *__restrict__ s_d,
-                                             const int (&joff)[C::NTW_MAX], int aoff, int g,
-                                             f32x4 (&acc)[C::MTC][C::NTW_MAX])
+                                             const int (&joff)[C::NTW_MAX], const int (&ml)[C::NTW_MAX],
+                                             const int (&mr)[C::NTW_MAX], int aoff, int g,
+                                             f32x4 (&acc)[C::MTC][C::NTW_MAX], float (&asum)[C::MTC])
 {
-    constexpr int SPR = C::PWD / 4;  // steps per row
+    constexpr int SPR = C::RUN ? 1 : C::PWD / 4;  // steps per row (halo-column layout)
     constexpr int S0 = KGI * C::STEPS / C::KG, S1 = (KGI + 1) * C::STEPS / C::KG;
     constexpr int LEN = S1 - S0;
     constexpr int PF = 2;
@@ -91,8 +120,8 @@ __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, cons
     for (int t = 0; t < NTW; ++t) xb[t] = joff[t] + g;
     auto load = [&](int i, float (&aa)[C::MTC], float (&bb)[NTW]) {
         const int s = S0 + i;
-        const int pd = 4 * s;                     // dy rows are PWD = 4*SPR wide: linear in s
-        const int px = 4 * s + 2 * (s / SPR);     // x rows are PWD + 2 wide
+        const int pd = 4 * s;                                     // dy: linear in s (rows are 4*SPR wide, or flat)
+        const int px = C::RUN ? 4 * s : 4 * s + 2 * (s / SPR);    // x rows are PWD + 2 wide, or flat with the same pitch
 #pragma unroll
         for (int m = 0; m < C::MTC; ++m) aa[m] = s_d[m * 16 * C::DPLANE + aoff + pd];
 #pragma unroll
@@ -107,8 +136,24 @@ __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, cons
         for (int t = 0; t < NTW; ++t) {
             float bv = b[i % (PF + 1)][t];
             if (RELU) bv = relu1(bv);  // the band was staged raw by LDS-DMA: the forward's ReLU-on-load is applied here
+            if constexpr (C::RUN) {
+                // pixel 4s + e sits in column (4s + e) % W: in the first column the x-1 taps, in the last the x+1 taps
+                // read a neighbouring row's pixel.  ml / mr hold the lane's pixel phase g when its column's tap is an
+                // x-1 / x+1 one (else -1), so one compare + select per operand, in the steps that touch a row end only.
+                // (i is a fully unrolled loop index: everything below folds to constants per step)
+                constexpr int W = C::WIDTH;
+                const int c0 = (4 * (S0 + i)) % W;
+                const int eL = c0 == 0 ? 0 : (W - c0 < 4 ? W - c0 : -1);          // phase whose column is 0
+                const int eR = (W - 1 - c0 < 4) ? W - 1 - c0 : -1;                // phase whose column is W-1
+                if (eL >= 0) bv = ml[t] == eL ? 0.f : bv;
+                if (eR >= 0) bv = mr[t] == eR ? 0.f : bv;
+            }
 #pragma unroll
             for (int m = 0; m < C::MTC; ++m) acc[m][t] = mfma16(a[i % (PF + 1)][m], bv, acc[m][t]);
+        }
+        if constexpr (!C::BIAS_IN_TILE) {
+#pragma unroll
+            for (int m = 0; m < C::MTC; ++m) asum[m] += a[i % (PF + 1)][m];  // db: step order, then lanes, K groups, slabs
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -117,15 +162,16 @@ __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, cons
 // dispatch on the (wave-uniform) K group and tile count of this wave
 template <class C, bool RELU, int KGI = 0>
 __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, const float *__restrict__ s_d,
-                                              const int (&joff)[C::NTW_MAX], int aoff, int g, int wt, int kg,
-                                              f32x4 (&acc)[C::MTC][C::NTW_MAX])
+                                              const int (&joff)[C::NTW_MAX], const int (&ml)[C::NTW_MAX],
+                                              const int (&mr)[C::NTW_MAX], int aoff, int g, int wt, int kg,
+                                              f32x4 (&acc)[C::MTC][C::NTW_MAX], float (&asum)[C::MTC])
 {
     constexpr int NLO = C::NTW_MAX > 1 ? C::NTW_MAX - 1 : 1;
     if (kg == KGI) {
-        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU, KGI>(s_x, s_d, joff, aoff, g, acc);
-        else if (C::NTW_MAX > 1) wgrad_k_loop<C, NLO, RELU, KGI>(s_x, s_d, joff, aoff, g, acc);
+        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU, KGI>(s_x, s_d, joff, ml, mr, aoff, g, acc, asum);
+        else if (C::NTW_MAX > 1) wgrad_k_loop<C, NLO, RELU, KGI>(s_x, s_d, joff, ml, mr, aoff, g, acc, asum);
     } else if constexpr (KGI + 1 < C::KG) {
-        wgrad_k_loops<C, RELU, KGI + 1>(s_x, s_d, joff, aoff, g, wt, kg, acc);
+        wgrad_k_loops<C, RELU, KGI + 1>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum);
     }
 }
 
@@ -143,7 +189,7 @@ struct WgradBatch {
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE, bool DY_POOLED = false>
 __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBatch batch, int n_images)
 {
-    using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
+    using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>(), wgrad_run<IN_MODE, DY_POOLED>()>;
     const void *__restrict__ in_ = batch.in[blockIdx.y];
     const float *__restrict__ dy = batch.dy[blockIdx.y];
     float *__restrict__ partial = batch.partial[blockIdx.y];
@@ -153,6 +199,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    PPO_STAMP(t_k0)
     const int wave = tid >> 6;
     const int wt = wave % C::WT;  // owner of N tiles wt, wt + WT, ...
     const int kg = wave / C::WT;  // K-split group
@@ -161,15 +208,22 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 
     // per-lane B offsets of this wave's n-tiles: j = (wt + 4*t)*16 + l15 -> (tap, ci); the bias column reads
     // the ones plane, padding columns the zeros plane
-    int joff[C::NTW_MAX];
+    int joff[C::NTW_MAX], ml[C::NTW_MAX], mr[C::NTW_MAX];
 #pragma unroll
     for (int t = 0; t < C::NTW_MAX; ++t) {
         const int j = (wt + C::WT * t) * 16 + l15;
         const int tap = j / C::CINP;
         const int ci = j % C::CINP;
-        joff[t] = j < 9 * C::CINP ? ci * C::XPLANE + (tap / 3) * C::PWX + (tap % 3)
-                                  : (j == 9 * C::CINP ? C::CINP * C::XPLANE : (C::CINP + 1) * C::XPLANE);
+        // halo-column layout: x of pixel (row r, column c) sits at r * PWX + c + 1; RUN: at G + r * W + c, i.e. the
+        // tap (ky, kx) of dy pixel q is at q + (G - 1) + ky * W + kx
+        joff[t] = j < 9 * C::CINP ? ci * C::XPLANE + (tap / 3) * C::PWX + (tap % 3) + (C::RUN ? C::G - 1 : 0)
+                                  : ((C::BIAS_IN_TILE && j == 9 * C::CINP) ? C::CINP * C::XPLANE : (C::CINP + 1) * C::XPLANE);
+        ml[t] = (j < 9 * C::CINP && tap % 3 == 0) ? g : -1;
+        mr[t] = (j < 9 * C::CINP && tap % 3 == 2) ? g : -1;
     }
+    float asum[C::MTC];
+#pragma unroll
+    for (int m = 0; m < C::MTC; ++m) asum[m] = 0.f;
     const int aoff = l15 * C::DPLANE + g;  // A: channel l15 of the m-tile, pixel +g
 
     f32x4 acc[C::MTC][C::NTW_MAX];
@@ -182,14 +236,20 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
     // LDS-DMA staging), then the constant planes
     zero_lds<C::NBUF * C::LDS_BUF, kWgradWaves * 64>(smem, tid);
     __syncthreads();
-    for (int b = 0; b < C::NBUF; ++b)
-        for (int i = tid; i < C::XPLANE; i += kWgradWaves * 64) s_x[b * C::LDS_BUF + C::CINP * C::XPLANE + i] = 1.0f;
+    if constexpr (C::BIAS_IN_TILE)
+        for (int b = 0; b < C::NBUF; ++b)
+            for (int i = tid; i < C::XPLANE; i += kWgradWaves * 64) s_x[b * C::LDS_BUF + C::CINP * C::XPLANE + i] = 1.0f;
 
     const int n_items = n_images * C::NBANDS;
     auto stage = [&](int item, float *bx, float *bd) {
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
-        if constexpr (IN_MODE == IN_U8)
+        if constexpr (C::RUN) {
+            stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
+            // the same routine for the TR rows y0 .. y0 + TR - 1 of dy: its first row is (y0 + 1) - 1, no guard
+            stage_band_chunk_dma<COUT, H, W, TR, C::DPLANE, 0, kWgradWaves>(dy, img, y0 + 1, bd, tid);
+            return;
+        } else if constexpr (IN_MODE == IN_U8)
             stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, bx, tid);
         else
             stage_band_dma<CIN, H, W, C::ROWS, C::PWX, C::XPLANE, 1, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
@@ -202,6 +262,8 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
         }
     };
     constexpr bool RELU = IN_MODE == IN_RELU;
+    PPO_STAMP(t_k1)
+    PPO_STAMP_ADD(6, t_k1, t_k0)  // prologue: lane constants, LDS zeroing
     if constexpr (C::NBUF == 2) {
         int buf = 0;
         if ((int)blockIdx.x < n_items) stage(blockIdx.x, s_x, s_d);
@@ -213,7 +275,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
             if (item + (int)gridDim.x < n_items)
                 stage(item + gridDim.x, s_x + (buf ^ 1) * C::LDS_BUF, s_d + (buf ^ 1) * C::LDS_BUF);
             PPO_STAMP(t_staged)
-            wgrad_k_loops<C, RELU>(bx, bd, joff, aoff, g, wt, kg, acc);
+            wgrad_k_loops<C, RELU>(bx, bd, joff, ml, mr, aoff, g, wt, kg, acc, asum);
             PPO_STAMP(t_end)
             PPO_STAMP_ADD(0, t_bar, t_top)      // barrier wait
             PPO_STAMP_ADD(1, t_staged, t_bar)   // DMA issue of the next item
@@ -227,7 +289,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
             __syncthreads();
             stage(item, s_x, s_d);
             __syncthreads();
-            wgrad_k_loops<C, RELU>(s_x, s_d, joff, aoff, g, wt, kg, acc);
+            wgrad_k_loops<C, RELU>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum);
         }
     }
 
@@ -235,23 +297,41 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
     // adds them in group order (fixed order: deterministic), then one slab per workgroup:
     // partial[wg][co][j]; a lane holds rows g*4+r (co), column l15 (j) of each of its tiles
     float *s_red = smem;
+    PPO_STAMP(t_k2)
     __syncthreads();  // every wave is done reading the staging buffers
-    if (kg > 0) {
-        float *img = s_red + (size_t)(kg - 1) * COUT * C::JP;
+    // db by lane sums: a lane summed dy[co = m*16 + l15][pixels = g (mod 4)] over its K steps; the four pixel phases are
+    // added across the lane groups (fixed order), K groups through the reduction images, workgroups through the slab
+    const bool db_lane = !C::BIAS_IN_TILE && wt == 0 && g == 0;
+    if constexpr (!C::BIAS_IN_TILE) {
 #pragma unroll
-        for (int m = 0; m < C::MTC; ++m)
-#pragma unroll
-            for (int t = 0; t < C::NTW_MAX; ++t)
-                if (wt + C::WT * t < C::NTT)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        img[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15] = acc[m][t][r];
+        for (int m = 0; m < C::MTC; ++m) {
+            float v = asum[m];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            asum[m] = v;
+        }
     }
-    __syncthreads();
-    if (kg == 0) {
+    // one image, the groups take turns (group order: deterministic); 2 barriers per group, once per kernel — a
+    // set of KG - 1 images was up to 117 KB of LDS, more than the staging buffers and the reason for one workgroup per CU
 #pragma unroll 1
-        for (int src = 1; src < C::KG; ++src) {
-            const float *img = s_red + (size_t)(src - 1) * COUT * C::JP;
+    for (int src = 1; src < C::KG; ++src) {
+        float *img = s_red;
+        if (kg == src) {
+            if (db_lane) {
+#pragma unroll
+                for (int m = 0; m < C::MTC; ++m) img[(m * 16 + l15) * C::JP + 9 * C::CINP] = asum[m];
+            }
+#pragma unroll
+            for (int m = 0; m < C::MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < C::NTW_MAX; ++t)
+                    if (wt + C::WT * t < C::NTT)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            img[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15] = acc[m][t][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
 #pragma unroll
             for (int m = 0; m < C::MTC; ++m)
 #pragma unroll
@@ -260,7 +340,12 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             acc[m][t][r] += img[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15];
+            if (db_lane) {
+#pragma unroll
+                for (int m = 0; m < C::MTC; ++m) asum[m] += img[(m * 16 + l15) * C::JP + 9 * C::CINP];
+            }
         }
+        if (src + 1 < C::KG) __syncthreads();  // the image is free again
     }
     if (kg == 0) {
         float *slab = partial + (size_t)blockIdx.x * COUT * C::JP;
@@ -272,7 +357,14 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         slab[(m * 16 + g * 4 + r) * C::JP + (wt + C::WT * t) * 16 + l15] = acc[m][t][r];
+        if (db_lane) {
+#pragma unroll
+            for (int m = 0; m < C::MTC; ++m) slab[(m * 16 + l15) * C::JP + 9 * C::CINP] = asum[m];
+        }
     }
+    PPO_STAMP(t_k3)
+    PPO_STAMP_ADD(7, t_k3, t_k2)  // K-group fold + slab write
+    PPO_STAMP_ADD(3, t_k3, t_k0)  // whole kernel, per wave
 }
 
 // dW[o][i][tap] = sum_wg partial[wg][o][tap*CINP + i]; db[o] = sum_wg partial[wg][o][9*CINP].
@@ -338,7 +430,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *
     }
 }
 
-constexpr int kWgradMaxSlabs = 512;
+#ifndef PPO_TUNE_WGRAD_MAXSLABS
+#define PPO_TUNE_WGRAD_MAXSLABS 512
+#endif
+constexpr int kWgradMaxSlabs = PPO_TUNE_WGRAD_MAXSLABS;
 
 // The same reduction for up to kMaxJobs layers in one launch (blockIdx.y = layer): a backward pass defers its
 // 15 slab reductions to one launch at the end instead of 15 small ones between the wgrad kernels.
@@ -414,7 +509,7 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
                  int n_images, int accumulate, hipStream_t st, int *n_slabs_out = nullptr,
                  const WgradBatch *more = nullptr, int count = 1, const uint8_t *argmax = nullptr)
 {
-    using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>()>;
+    using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>(), wgrad_run<IN_MODE, DY_POOLED>()>;
     auto kern = conv3x3_wgrad_kernel<CIN, COUT, H, W, TR, IN_MODE, DY_POOLED>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -426,8 +521,10 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
     const int n_items = n_images * C::NBANDS;
     // as many workgroups as fit on the chip at once (LDS-limited), at most kWgradMaxSlabs slabs
     int per_cu = (int)((160 * 1024) / C::LDS_BYTES);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    per_cu = per_cu < 1 ? 1 : (per_cu > PPO_TUNE_WGRAD_PERCU ? PPO_TUNE_WGRAD_PERCU : per_cu);
+#ifndef PPO_TUNE_WGRAD_BIGSLABS
     if ((size_t)COUT * C::JP * sizeof(float) > 16 * 1024) per_cu = 1;  // big slabs: keep the reduce traffic down
+#endif
     int grid = 256 * per_cu;
     if (grid > kWgradMaxSlabs) grid = kWgradMaxSlabs;
     if (grid > n_items) grid = n_items;

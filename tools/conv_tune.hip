@@ -99,6 +99,9 @@ int main(int argc, char **argv)
                 const double n = (double)st[5];
                 printf("    per item-wave cycles: barrier+stage %.0f | group prologue %.0f | K loop %.0f | compute section %.0f | item %.0f  (item-waves %.0f)\n",
                        st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, n);
+                if (which == 2)
+                    printf("    wgrad per wave: prologue %.0f | fold+slab %.0f | whole kernel %.0f   (waves %d, items per wave %.1f)\n",
+                           st[6] / 2048.0, st[7] / 2048.0, st[3] / 2048.0, 2048, n / 2048.0);
             }
 #endif
             fflush(stdout);
