@@ -267,12 +267,14 @@ int ppo_tanh_backward_f32(const float *dy, const float *y, float *dx, size_t n, 
  * V_i = heads[b, value_col + i]; P_k = heads[b, tvf_col + k*tvf_stride] (the `ext` column of TVF head k);
  * returns [*,n_value_heads], tvf_returns [*,n_tvf], tvf_weights [n_tvf] (nullable = 1).  dheads [B,ldo] gets
  * grad_scale * d loss_b / d heads over the WHOLE row (zeros elsewhere).  stats (nullable) [B,4]: value
- * loss, TVF loss, total, 0.  index as in ppo_ppo_loss_f32.
+ * loss, TVF loss, total, 0.  index as in ppo_ppo_loss_f32.  tvf_keep_prob < 1: horizon dropout (rl/tvf.py:64-69) — each
+ * (sample, head) TVF term is kept with that probability and weighted 1 / tvf_keep_prob, drawn from the counter-based
+ * generator of ppo_policy_act_f32 at (seed, offset + b * n_tvf + k); 1 = off.
  */
 int ppo_value_loss_f32(const float *heads, int B, int ldo, int value_col, int n_value_heads, const float *returns,
                        float vf_coef, int tvf_col, int n_tvf, int tvf_stride, const float *tvf_returns,
                        const float *tvf_weights, float tvf_coef, float grad_scale, float *dheads, float *stats,
-                       const int32_t *index, void *stream);
+                       const int32_t *index, float tvf_keep_prob, uint64_t seed, uint64_t offset, void *stream);
 
 /*
  * Distillation-phase loss (Runner.train_distil_minibatch, rl/rollout.py:1331-1449; value_loss "mse"):

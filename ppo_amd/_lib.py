@@ -71,7 +71,7 @@ SIGNATURES = {
     "ppo_conv3x3_wgrad_reduce_f32": (_i, [_vp, _i, _vp]),
     "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),
     "ppo_tanh_backward_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),
-    "ppo_value_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "ppo_value_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _u64, _u64, _vp]),
     "ppo_distil_loss_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "ppo_gaussian_act_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ppo_gaussian_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),

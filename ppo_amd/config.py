@@ -125,9 +125,15 @@ class TVFConfig(_Group):  # rl/config.py:209-246
         ("return_samples", int, 8, "n-step samples per horizon"),
         ("return_use_log_interpolation", bool, False, "interpolate in log-horizon space"),
         ("include_ext", bool, False, "also train the ext value head in the value phase"),
-        ("trimming", str, "off", "[off]  (horizon trimming is not built)"),
+        ("trimming", str, "off", "[off|timelimit|est_term] reduce horizons past the episode end to the time left (:217)"),
+        ("trimming_mode", str, "average", "[interpolate|average|substitute|random] (:218)"),
+        ("trim_advantages", str, "trimmed", "[trimmed|untrimmed|average] value estimate used for advantages (:219)"),
+        ("trim_clip", float, -1.0, "if >= 0 clips how much trimming can change a value estimate (:220)"),
+        ("eta_minh", int, 128, "estimated-termination trimming: minimum horizon (:221)"),
+        ("eta_buffer", int, 32, "estimated-termination trimming: steps added to the percentile (:222)"),
+        ("eta_percentile", float, 90.0, "estimated-termination trimming: percentile of episode lengths (:223)"),
         ("head_weighting", str, "off", "[off|h_weighted]"),
-        ("horizon_dropout", float, 0.0, "must be 0 (not built)"),
+        ("horizon_dropout", float, 0.0, "fraction of horizons excluded per sample in the TVF loss (:224)"),
     )
 
 
@@ -285,6 +291,8 @@ class Config:
             raise ValueError("Invalid clip_mode.")
         if self.tvf.gamma is None:
             self.tvf.gamma = self.gamma
+        if self.env.timeout == 0:  # EnvConfig.auto, rl/config.py:579-600
+            self.env.timeout = {"atari": 27000, "procgen": 1000, "mujoco": 1001}.get(self.env.type, 0)
         if self.restore in ("True", "true", True):  # rl/config.py:810-812
             self.restore = "always"
         if self.restore not in ("always", "never", "auto"):

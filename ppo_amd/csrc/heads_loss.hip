@@ -57,12 +57,21 @@ __global__ __launch_bounds__(256) void tanh_backward_kernel(const float *__restr
 
 enum { VS_VALUE = 0, VS_TVF, VS_TOTAL, VS_SPARE, VS_N };
 
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+
 // 4 samples per 256-thread block, one wave each
 __global__ __launch_bounds__(256) void value_loss_kernel(
     const float *__restrict__ heads, int B, int ldo, int value_col, int vh, const float *__restrict__ returns,
     float vf_coef, int tvf_col, int K, int tvf_stride, const float *__restrict__ tvf_returns,
     const float *__restrict__ tvf_weights, float tvf_coef, float grad_scale, float *__restrict__ dheads,
-    float *__restrict__ stats, const int32_t *__restrict__ index)
+    float *__restrict__ stats, const int32_t *__restrict__ index, float keep_prob, uint64_t seed, uint64_t offset)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -80,7 +89,10 @@ __global__ __launch_bounds__(256) void value_loss_kernel(
             g = 2.f * vf_coef * diff;
         } else if (tvf_returns && c >= tvf_col && c < tvf_col + K * tvf_stride && (c - tvf_col) % tvf_stride == 0) {
             const int k = (c - tvf_col) / tvf_stride;
-            const float w = tvf_weights ? tvf_weights[k] : 1.f;
+            float w = tvf_weights ? tvf_weights[k] : 1.f;
+            // horizon dropout (rl/tvf.py:64-69): each (sample, head) term is kept with probability keep_prob and
+            // weighted 1 / keep_prob; the draw is a counter-based uniform keyed by (seed, offset + b * K + k)
+            if (keep_prob < 1.f) w = uniform01(seed, offset + (uint64_t)b * K + k) < keep_prob ? w / keep_prob : 0.f;
             const float diff = z[c] - tvf_returns[(size_t)sb * K + k];
             tloss += 0.5f * tvf_scale * w * diff * diff;
             g = tvf_scale * w * diff;
@@ -163,15 +175,6 @@ __global__ __launch_bounds__(256) void distil_loss_kernel(
             s[DS_SQERR] = sq / n_pred;
         }
     }
-}
-
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter)
-{
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
 }
 
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
@@ -303,7 +306,8 @@ extern "C" int ppo_tanh_backward_f32(const float *dy, const float *y, float *dx,
 extern "C" int ppo_value_loss_f32(const float *heads, int B, int ldo, int value_col, int n_value_heads,
                                   const float *returns, float vf_coef, int tvf_col, int n_tvf, int tvf_stride,
                                   const float *tvf_returns, const float *tvf_weights, float tvf_coef, float grad_scale,
-                                  float *dheads, float *stats, const int32_t *index, void *stream)
+                                  float *dheads, float *stats, const int32_t *index, float tvf_keep_prob, uint64_t seed,
+                                  uint64_t offset, void *stream)
 {
     using namespace ppo;
     if (B < 0 || ldo <= 0 || n_value_heads < 0 || n_tvf < 0 || value_col < 0 || value_col + n_value_heads > ldo)
@@ -311,13 +315,14 @@ extern "C" int ppo_value_loss_f32(const float *heads, int B, int ldo, int value_
     if (n_tvf > 0 && (tvf_stride <= 0 || tvf_col < 0 || tvf_col + (n_tvf - 1) * tvf_stride >= ldo))
         return fail(PPO_E_INVALID, "ppo_value_loss_f32: TVF columns [%d + k*%d, k < %d) exceed the row (%d)", tvf_col,
                     tvf_stride, n_tvf, ldo);
+    if (!(tvf_keep_prob > 0.f)) return fail(PPO_E_INVALID, "ppo_value_loss_f32: tvf_keep_prob must be in (0, 1]");
     if (B == 0) return PPO_OK;
     if (!heads || !dheads) return fail(PPO_E_INVALID, "ppo_value_loss_f32: null pointer");
     if (n_tvf == 0) tvf_returns = nullptr;
     if (n_value_heads == 0) returns = nullptr;
     hipLaunchKernelGGL(value_loss_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), heads, B, ldo, value_col,
                        n_value_heads, returns, vf_coef, tvf_col, n_tvf, n_tvf > 0 ? tvf_stride : 1, tvf_returns,
-                       tvf_weights, tvf_coef, grad_scale, dheads, stats, index);
+                       tvf_weights, tvf_coef, grad_scale, dheads, stats, index, tvf_keep_prob, seed, offset);
     return check_launch("value_loss_kernel");
 }
 

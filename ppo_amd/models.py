@@ -1011,14 +1011,16 @@ class DualHeadNet:
         return stats
 
     def value_minibatch(self, prev_state, returns=None, tvf_returns=None, tvf_weights=None, vf_coef=0.5,
-                        tvf_coef=1.0, loss_scale=1.0, index=None):
-        """Value phase (Runner.train_value_minibatch, rl/rollout.py:1513-1567; TVF loss rl/tvf.py:32-77)."""
+                        tvf_coef=1.0, loss_scale=1.0, index=None, tvf_keep_prob=1.0, dropout_seed=0, dropout_offset=0):
+        """Value phase (Runner.train_value_minibatch, rl/rollout.py:1513-1567; TVF loss rl/tvf.py:32-77, with
+        horizon dropout when tvf_keep_prob < 1: :64-69)."""
         acts, o, B, dheads = self._train_forward(prev_state)
         stats = self._buf("value_stats", (B, 4))
         self._call("ppo_value_loss_f32", _p(o), B, self.nh, self.col_value, self.vh if returns is not None else 0,
                    _p(returns), float(vf_coef), self.col_tvf if self.K else 0, self.K if tvf_returns is not None else 0,
                    max(self.vh, 1), _p(tvf_returns), _p(tvf_weights), float(tvf_coef), float(loss_scale) / B, _p(dheads),
-                   _p(stats), _p(index))
+                   _p(stats), _p(index), float(tvf_keep_prob), int(dropout_seed) & (2**64 - 1),
+                   int(dropout_offset) & (2**64 - 1))
         self.backward(acts, dheads)
         return stats
 

@@ -118,6 +118,8 @@ class Runner:
         self._rewards_host = torch.zeros((N, A), dtype=torch.float32).pin_memory()
         self._dones_host = torch.zeros((N, A), dtype=torch.uint8).pin_memory()
         self.obs = None  # current observation (host), set by reset()
+        self.all_time = np.zeros((N + 1, A), np.int32)  # env time of every recorded state (rl/rollout.py:808 all_time)
+        self._finished_lengths = [[] for _ in range(N)]  # lengths of the episodes that ended at each env step
         self.time = np.zeros(A, np.int32)
         self.episode_score = np.zeros(A, np.float32)
         self.episode_len = np.zeros(A, np.int32)
@@ -284,6 +286,9 @@ class Runner:
         """rl/rollout.py:520-556: reset envs and per-env bookkeeping."""
         assert self.vec_env is not None, "Please assign vec_env first."
         self.obs = self.vec_env.reset()
+        if self.tvf is not None:
+            self.tvf.episode_length_buffer.clear()
+            self.tvf.episode_length_buffer.append(1000)  # rl/rollout.py:553-555
         self.time[:] = 0
         self.episode_score[:] = 0
         self.episode_len[:] = 0
@@ -354,11 +359,15 @@ class Runner:
         if self.dual:
             self.value[t, lo:hi].copy_(hv[:, val.col_value:val.col_value + self.VH])
         if self.tvf is not None:
-            self.tvf.tvf_value[t, lo:hi].copy_(hv[:, val.col_tvf:].view(B, val.K, self.VH))
+            rec = self.tvf.tvf_untrimmed_value  # == tvf_value unless --tvf_trimming
+            rec[t, lo:hi].copy_(hv[:, val.col_tvf:].view(B, val.K, self.VH))
+            rec[t, lo:hi, 0].zero_()  # the first value head (h = 0) is zero by definition (rl/rollout.py:791)
 
-    def _log_finished(self, finished, ep_len, ep_score):
+    def _log_finished(self, finished, ep_len, ep_score, t=None):
         if finished.any():
             self.ep_count += int(finished.sum())
+            if t is not None:
+                self._finished_lengths[t].extend(int(x) for x in np.asarray(ep_len)[finished])
             for s, l in zip(ep_score[finished][:8], ep_len[finished][:8]):
                 self.log.watch_full("ep_score", s, history_length=100)
                 self.log.watch_full("ep_length", l, history_length=100)
@@ -371,6 +380,7 @@ class Runner:
         other (the reference overlaps nothing: rl/rollout.py:792-816 is forward -> sync -> step)."""
         assert self.vec_env is not None, "Please attach vector environment first."
         N, A = self.N, self.A
+        self._finished_lengths = [[] for _ in range(N)]
         env = self.vec_env
         parts = getattr(env, "parts", [env])
         if all(hasattr(p, "step_arrays") for p in parts) and self.model.obs_norm is None:
@@ -379,11 +389,14 @@ class Runner:
             self._rollout_generic(env)
         self.ext_rewards.copy_(self._rewards_host, non_blocking=True)
         self.terminals.view(torch.uint8).copy_(self._dones_host, non_blocking=True)
+        if self.tvf is not None:
+            self.tvf.apply_trimming(self.all_time, self._finished_lengths)  # no-op unless --tvf_trimming
         self._sample_calls += N + 1
         self.step += N * A * self.world
 
     def _rollout_pipelined(self, parts):
         N = self.N
+        self.all_time[0] = self.time
         rew_np, done_np = self._rewards_host.numpy(), self._dones_host.numpy()
         act_np = self._actions_host.numpy()
         bounds = np.cumsum([0] + [p.num_envs for p in parts]).tolist()
@@ -431,8 +444,10 @@ class Runner:
             lo, hi = bounds[i], bounds[i + 1]
             events[i].synchronize()
             parts[i].step_arrays(act_np[lo:hi], rew_np[t, lo:hi], done_np[t, lo:hi])
-            _, ep_len, ep_score = parts[i].last_episode_stats
-            self._log_finished(done_np[t, lo:hi].astype(bool), ep_len, ep_score)
+            time_now, ep_len, ep_score = parts[i].last_episode_stats
+            done = done_np[t, lo:hi].astype(bool)
+            self.all_time[t + 1, lo:hi] = np.where(done, 0, time_now)  # a finished env shows the first state of a new episode
+            self._log_finished(done, ep_len, ep_score, t)
 
         tags = [f"i{i}" if P > 1 else "i" for i in range(P)]
         host_rows = [self._actions_host[bounds[i]:bounds[i + 1]] for i in range(P)]
@@ -449,6 +464,7 @@ class Runner:
             if s_ is not main:
                 main.wait_stream(s_)
         main.wait_stream(copy_stream)  # the graph path's last all_obs rows are written by D2D copies queued there
+        self.time = self.all_time[N].copy()
         self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
 
     def _rollout_generic(self, env):
@@ -462,6 +478,7 @@ class Runner:
         act_np = self._actions_host.numpy()
         stream = torch.cuda.current_stream()
         for t in range(N + 1):
+            self.all_time[t] = self.time
             self.all_obs[t].copy_(torch.from_numpy(np.ascontiguousarray(self.obs)), non_blocking=True)
             if norm is not None and t < N:
                 norm.update(self.all_obs[t])
@@ -473,8 +490,9 @@ class Runner:
             self.obs, rew, dones, infos = env.step(act_np.copy())
             rew_np[t] = rew
             done_np[t] = dones
+            self.time = np.asarray([i.get("time", 0) for i in infos], np.int32)  # rl/rollout.py:753
             self._log_finished(np.asarray(dones, bool), np.asarray([i.get("ep_length", 0) for i in infos]),
-                               np.asarray([i.get("ep_score", 0.0) for i in infos]))
+                               np.asarray([i.get("ep_score", 0.0) for i in infos]), t)
 
     @torch.no_grad()
     def detached_batch_forward(self, obs, aux_features=None, max_batch_size=None, **kwargs):
@@ -595,9 +613,14 @@ class Runner:
         weights = self._tvf_value_weights_dev if self.tvf is not None else None
         net.zero_untouched_grads()
 
+        keep = 1.0 - args.tvf.horizon_dropout if self.tvf is not None else 1.0
+        seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + 7919 * (self.rank + 1)
+
         def step(mb_obs, idx):
+            off = self.tvf.next_dropout_offset(mb_obs.shape[0] * self.K) if keep < 1.0 else 0
             return net.value_minibatch(mb_obs, returns=returns, tvf_returns=tvf_returns, tvf_weights=weights,
-                                       vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=1.0, index=idx)
+                                       vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=1.0, index=idx,
+                                       tvf_keep_prob=keep, dropout_seed=seed, dropout_offset=off)
         self._run_epochs("value", self.value_optimizer, args.value_opt.epochs, args.value_opt.mini_batch_size, step, 4)
 
     def wants_distil_update(self, location=None):
@@ -771,7 +794,9 @@ class Runner:
         state, its reward normaliser, its host RNG (minibatch permutations) — is gathered to rank 0 and stored as one
         entry per rank.  Every rank must call this (it is a collective when world > 1)."""
         from . import checkpoint
-        local = {"np_random": np.random.get_state(), "ep_count": self.ep_count}
+        local = {"np_random": np.random.get_state(), "ep_count": self.ep_count, "time": self.time.copy()}
+        if self.tvf is not None:
+            local["episode_length_buffer"] = [int(x) for x in self.tvf.episode_length_buffer]  # rl/rollout.py:399
         if not disable_env_state and self.vec_env is not None:
             local["env_state"] = checkpoint.save_env_state(self.vec_env)
         per_rank = [local]
@@ -815,6 +840,11 @@ class Runner:
             if mine.get("np_random") is not None:
                 np.random.set_state(mine["np_random"])
             self.ep_count = mine.get("ep_count", self.ep_count)
+            if mine.get("time") is not None:
+                self.time = np.asarray(mine["time"], np.int32).copy()
+            if self.tvf is not None and mine.get("episode_length_buffer") is not None:
+                self.tvf.episode_length_buffer.clear()
+                self.tvf.episode_length_buffer.extend(mine["episode_length_buffer"])
             if mine.get("env_state") and self.vec_env is not None:
                 checkpoint.restore_env_state(self.vec_env, mine["env_state"])
                 if hasattr(self.vec_env, "parts"):

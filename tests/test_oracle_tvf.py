@@ -92,3 +92,34 @@ def test_product_interpolation_plan_matches_oracle():
             assert mode == 2 and (i0, i1) == (o[1], o[2]) and w0 == float(1 - o[3]) and w1 == float(o[3])
     with pytest.raises(IndexError):
         plan(hz, 65)
+
+
+def test_trim_horizons_matches_reference_bitwise(golden_dir):
+    """ppo_amd.tvf.trim_horizons against the reference's TVFRunnerModule.trim_horizons (rl/tvf.py:91-208) run on CPU
+    (tests/golden/make_tvf_trim_golden.py): every method x mode, with and without trim_clip, two horizon sets —
+    trimmed estimates, the advantage value (mean over valid horizons) and the time till termination, bit for bit."""
+    import json
+    from ppo_amd import tvf
+    g = np.load(os.path.join(golden_dir, "tvf_trim_golden.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "tvf_trim_golden.json")))
+    assert len(meta["cases"]) == 32
+    for c in meta["cases"]:
+        t = c["tag"]
+        np.random.seed(c["seed"])  # mode "random" draws from np.random in the reference's order
+        trimmed, final, ttt = tvf.trim_horizons(
+            g[f"horizons_{c['n_heads']}"], g[t + "_values"], g[t + "_time"], c["timeout"], method=c["method"],
+            mode=c["mode"], trim_clip=c["trim_clip"], episode_lengths=g[t + "_buffer"].tolist(),
+            eta_percentile=c["eta_percentile"], eta_buffer=c["eta_buffer"], eta_minh=c["eta_minh"])
+        what = (c["method"], c["mode"], c["trim_clip"])
+        assert trimmed.shape == g[t + "_trimmed"].shape and str(trimmed.dtype) == c["trimmed_dtype"], what
+        assert np.array_equal(trimmed, g[t + "_trimmed"]), what
+        assert final.dtype == np.float32 and np.array_equal(final, g[t + "_final"]), what
+        assert str(np.asarray(ttt).dtype) == c["ttt_dtype"] and np.array_equal(ttt, g[t + "_ttt"]), what
+        assert not np.array_equal(trimmed[..., 0], g[t + "_values"][..., 0]), "the case trims nothing"
+    trimmed, final, ttt = tvf.trim_horizons(g[f"horizons_{meta['off']['n_heads']}"], g["off_values"],
+                                            np.zeros(len(g["off_values"]), np.int32), 1000, method="off")
+    assert np.array_equal(trimmed, g["off_trimmed"]) and final == 0 and ttt is None
+    with pytest.raises(ValueError):
+        tvf.trim_horizons(g["horizons_16"], g["c0_values"], g["c0_time"], 1000, method="nope")
+    with pytest.raises(ValueError):
+        tvf.trim_horizons(g["horizons_16"], g["c0_values"], g["c0_time"], 1000, mode="nope")

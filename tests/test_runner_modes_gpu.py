@@ -181,8 +181,10 @@ def test_gaussian_tvf_dual_runner_matches_oracle_returns(tmp_path):
     noise = (r.actions - r.raw_policy) / std
     assert abs(float(noise.mean())) < 0.15 and 0.8 < float(noise.std()) < 1.2
     # TVF estimates recorded from value_net
-    tv = model.value_net.forward(r.all_obs[7].contiguous())["tvf_value"]
+    tv = model.value_net.forward(r.all_obs[7].contiguous())["tvf_value"].clone()
+    tv[:, 0] = 0  # the h = 0 head is zero by definition when recorded (rl/rollout.py:791)
     assert tv.shape == (A, K, 1) and torch.allclose(tv, r.tvf.tvf_value[7], atol=1e-6)
+    assert float(r.tvf.tvf_value[:, :, 0].abs().max()) == 0.0
     # returns: GAE on the longest horizon, TVF targets = oracle on the same NumPy draws
     np.random.seed(123)
     r.calculate_returns()
@@ -220,3 +222,77 @@ def test_gaussian_tvf_dual_runner_matches_oracle_returns(tmp_path):
     assert torch.equal(model.value_net.flat, v) and torch.equal(r.distil_optimizer.state.exp_avg, m)
     out = r.detached_batch_forward(r.all_obs[:4].reshape(-1, 11), output="default", max_batch_size=16)
     assert out["tvf_value"].shape == (32, K, 1) and out["raw_policy"].shape == (32, 3)
+
+
+def test_tvf_trimming_and_horizon_dropout_through_the_runner():
+    """--tvf_trimming (rl/tvf.py:91-208 called per env step at rl/rollout.py:788-804, 884-892): the Runner records the
+    untrimmed estimates and env times, trims the rollout step by step with the episode-length buffer growing as the
+    rollout did, and GAE reads the value `--tvf_trim_advantages` names.  --tvf_horizon_dropout (rl/tvf.py:64-69):
+    each (sample, head) TVF term kept with probability 1 - p and weighted 1 / (1 - p)."""
+    args.setup(["--agents=8", "--n_steps=32", "--model_architecture=dual", "--model_encoder=mlp",
+                "--model_hidden_units=64", "--env_type=mujoco", "--env_name=Fake", "--seed=9", "--device=cuda",
+                "--tvf_enabled=True", "--tvf_value_heads=8", "--tvf_max_horizon=100", "--tvf_return_samples=4",
+                "--tvf_trimming=est_term", "--tvf_trimming_mode=average", "--tvf_trim_advantages=average",
+                "--tvf_eta_minh=4", "--tvf_eta_buffer=2", "--env_timeout=30", "--tvf_horizon_dropout=0.5",
+                "--policy_opt_mini_batch_size=64", "--value_opt_mini_batch_size=64", "--distil_opt_mini_batch_size=64",
+                "--env_reward_normalization=off", "--disable_logging=True"])
+    torch.manual_seed(9)
+    np.random.seed(9)
+    horizons, weights = tvf.get_value_head_horizons(args.tvf.value_heads, args.tvf.max_horizon, args.tvf.head_spacing,
+                                                    include_weight=True)
+    model = models.TVFModel("mlp", input_dims=(11,), actions=3, device="cuda", architecture="dual", hidden_units=64,
+                            encoder_activation_fn="tanh", tvf_fixed_head_horizons=horizons,
+                            tvf_fixed_head_weights=weights, head_scale=0.1, head_bias=True)
+    r = rollout.Runner(model, logger.Logger(quiet=True), action_dist="gaussian")
+    r.vec_env = FloatVecEnv(8, 11, seed=4)
+    r.reset()
+    assert list(r.tvf.episode_length_buffer) == [1000]
+    r.generate_rollout()
+    r.generate_rollout()  # the second rollout starts with a warm episode-length buffer and non-zero env times
+    torch.cuda.synchronize()
+    N, A, K = r.N, r.A, len(horizons)
+    assert r.tvf.tvf_untrimmed_value is not r.tvf.tvf_value
+    untrimmed = r.tvf.tvf_untrimmed_value.cpu().numpy()
+    assert r.all_time.shape == (N + 1, A) and r.all_time.max() > 10 and np.array_equal(r.all_time[N], r.time)
+    # replay: the reference's per-step call, buffer as it stood at each step
+    import collections
+    finished_first = sum(len(x) for x in r._finished_lengths)
+    assert finished_first > 0
+    buf = collections.deque(list(r.tvf.episode_length_buffer)[:len(r.tvf.episode_length_buffer) - finished_first], maxlen=1000)
+    trimmed_any = False
+    for t in range(N + 1):
+        want, final, _ = tvf.trim_horizons(horizons, untrimmed[t], r.all_time[t], 30, method="est_term", mode="average",
+                                           trim_clip=-1, episode_lengths=buf, eta_percentile=args.tvf.eta_percentile,
+                                           eta_buffer=2, eta_minh=4)
+        assert np.array_equal(r.tvf.tvf_value[t].cpu().numpy(), want), t
+        assert np.array_equal(r.tvf.tvf_final_value[t].cpu().numpy(), final), t
+        trimmed_any |= not np.array_equal(want, untrimmed[t])
+        if t < N:
+            buf.extend(r._finished_lengths[t])
+    assert trimmed_any, "no state came close enough to the time limit to be trimmed"
+    # advantages from the mean over valid horizons
+    r.calculate_returns()
+    ext = r.tvf.tvf_final_value.cpu().numpy()
+    oa, _ = O.gae_and_returns(r.ext_rewards.cpu().numpy(), ext[:N], ext[N], r.terminals.cpu().numpy(), args.gamma,
+                              args.lambda_policy, args.lambda_value)
+    assert np.abs(r.advantage.cpu().numpy() - oa).max() <= 1e-5 * np.abs(oa).max()
+    # horizon dropout in the value phase: about half of the (sample, head) terms survive, each weighted 2x
+    net = model.value_net
+    B = 64
+    obs = r.all_obs[:8].reshape(B, 11).contiguous()
+    tvf_ret = r.tvf.tvf_returns[:8, :, :, 0].reshape(B, K).contiguous()
+    w = torch.ones(K, device="cuda")
+    net.value_minibatch(obs, tvf_returns=tvf_ret, tvf_weights=w, tvf_coef=1.0)
+    full = net._buf("dheads", (B, net.nh))[:, net.col_tvf:].clone()
+    net.value_minibatch(obs, tvf_returns=tvf_ret, tvf_weights=w, tvf_coef=1.0, tvf_keep_prob=0.5, dropout_seed=5, dropout_offset=0)
+    d1 = net._buf("dheads", (B, net.nh))[:, net.col_tvf:].clone()
+    net.value_minibatch(obs, tvf_returns=tvf_ret, tvf_weights=w, tvf_coef=1.0, tvf_keep_prob=0.5, dropout_seed=5, dropout_offset=B * K)
+    d2 = net._buf("dheads", (B, net.nh))[:, net.col_tvf:].clone()
+    live = full != 0
+    kept = (d1 != 0) & live
+    assert 0.35 < float(kept.sum()) / float(live.sum()) < 0.65
+    assert torch.allclose(d1[kept], 2 * full[kept], rtol=1e-6) and not torch.equal(d1, d2)
+    r.train()
+    torch.cuda.synchronize()
+    stats = r.fetch_stats()
+    assert np.isfinite(stats["loss_tvf"]) and stats["loss_tvf"] > 0 and r.tvf._dropout_calls > 0
