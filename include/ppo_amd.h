@@ -345,6 +345,9 @@ size_t ppo_moments_workspace_bytes(void);
 int ppo_moments_f64(const float *x, int64_t n, double *moments, void *workspace, void *stream);
 int ppo_normalize_f32(const float *x, int64_t n, const double *moments, float eps, float *out, float *mean_std_out,
                       void *stream);
+/* dst[i] += src[i], i < n: gradient accumulation over the micro-batches of a minibatch (Runner.train_batch,
+ * rl/rollout.py:2331-2374, where autograd accumulates into .grad across `loss_scale = 1 / micro_batches` passes). */
+int ppo_accumulate_f32(float *dst, const float *src, int64_t n, void *stream);
 
 /*
  * Truncated-horizon (TVF) returns: the sampled weighted-n-step estimator of

@@ -99,6 +99,25 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict_
     }
 }
 
+// dst += src, four floats per thread where the pair is 16-byte aligned (micro-batch gradient accumulation)
+__global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n,
+                                                         int vec)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (4 * i + 3 < n) {
+            float4 d = reinterpret_cast<float4 *>(dst)[i];
+            const float4 v = reinterpret_cast<const float4 *>(src)[i];
+            d.x += v.x, d.y += v.y, d.z += v.z, d.w += v.w;
+            reinterpret_cast<float4 *>(dst)[i] = d;
+        } else {
+            for (int64_t k = 4 * i; k < n; ++k) dst[k] += src[k];
+        }
+    } else if (i < n) {
+        dst[i] += src[i];
+    }
+}
+
 }  // namespace
 }  // namespace ppo
 
@@ -140,4 +159,17 @@ extern "C" int ppo_normalize_f32(const float *x, int64_t n, const double *moment
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n,
                        moments, eps, out, mean_std_out);
     return check_launch("normalize_kernel");
+}
+
+extern "C" int ppo_accumulate_f32(float *dst, const float *src, int64_t n, void *stream)
+{
+    using namespace ppo;
+    if (n < 0) return fail(PPO_E_INVALID, "ppo_accumulate_f32: n < 0");
+    if (n == 0) return PPO_OK;
+    if (!dst || !src) return fail(PPO_E_INVALID, "ppo_accumulate_f32: null pointer");
+    const int vec = aligned(dst, 16) && aligned(src, 16);
+    const int64_t threads = vec ? (n + 3) / 4 : n;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), dst, src,
+                       n, vec);
+    return check_launch("accumulate_kernel");
 }

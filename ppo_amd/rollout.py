@@ -544,20 +544,56 @@ class Runner:
                       grad_div=float(self.world), grad_norm_out=self._grad_norm, state=opt.state)
         return self._grad_norm
 
+    def _micro_batches(self, mb, force_micro_batch_size=None):
+        """(micro-batch size, count) of a per-rank minibatch of mb samples (rl/rollout.py:2310-2316): the reference
+        splits a minibatch into passes of at most --max_micro_batch_size samples whose gradients accumulate."""
+        micro = force_micro_batch_size if force_micro_batch_size is not None else min(args.max_micro_batch_size, mb)
+        if micro <= 0 or mb % micro:
+            raise ValueError(f"minibatch {mb} is not a multiple of the micro-batch size {micro}")
+        return micro, mb // micro
+
+    class _Accumulator:
+        """Gradient accumulation over the micro-batches of one minibatch.  Every backward pass of the HIP path
+        OVERWRITES net.grad, so passes 2.. are added into a second flat buffer (ppo_accumulate_f32) and the sum is
+        copied back before the optimiser step; with one micro-batch nothing happens.  The data-parallel early-bucket
+        hook is parked meanwhile: only the accumulated gradient may leave."""
+
+        def __init__(self, runner, net, count):
+            self.r, self.net, self.count, self.k = runner, net, count, 0
+            self.hook = net.grad_ready_hook
+            if count > 1:
+                net.grad_ready_hook = None
+                self.acc = net._buf("grad_accum", tuple(net.grad.shape))
+
+        def after_backward(self):
+            if self.count > 1:
+                if self.k == 0:
+                    self.acc.copy_(self.net.grad)
+                else:
+                    self.r._call("ppo_accumulate_f32", _p(self.acc), _p(self.net.grad), self.net.grad.numel())
+            self.k += 1
+
+        def finish(self):
+            if self.count > 1:
+                self.net.grad.copy_(self.acc)
+                self.net.grad_ready_hook = self.hook
+
     def _run_epochs(self, label, optimizer, epochs, mini_batch_size, step_fn, n_stats):
         """Permutation minibatching over the rollout (rl/rollout.py:2257-2407): per epoch one host shuffle
-        (np.random, as the reference :2319-2320); per minibatch gather the observations, run
-        step_fn(mb_obs, index) -> per-sample stats [mb, n_stats], step the optimiser; the stats are column-
-        summed into one device row per minibatch."""
+        (np.random, as the reference :2319-2320); per minibatch — in micro-batches of at most --max_micro_batch_size
+        samples, gradients accumulated, each pass scaled by 1 / micro_batches (:2331-2374) — gather the observations,
+        run step_fn(mb_obs, index, loss_scale) -> per-sample stats [n, n_stats], then step the optimiser; the stats
+        are column-summed into one device row per minibatch."""
         B = self.N * self.A
         net = optimizer.net
         mb = parallel.local_minibatch(mini_batch_size)  # the flag is the GLOBAL minibatch (SURVEY.md §8e)
         if B % mb:
             raise ValueError(f"batch {B} is not a multiple of the per-rank minibatch {mb}")
         n_mb = B // mb
+        micro, n_micro = self._micro_batches(mb)
         obs_rows = self.all_obs[:self.N].view(B, -1)
         row_bytes = obs_rows.shape[1] * obs_rows.element_size()
-        mb_obs = net._buf("mb_obs", (mb, *self.state_shape), self.all_obs.dtype)
+        mb_obs = net._buf("mb_obs", (micro, *self.state_shape), self.all_obs.dtype)
         stat_rows = net._buf(f"stat_rows_{label}", (epochs * n_mb, n_stats))
         norm_rows = net._buf(f"norm_rows_{label}", (epochs * n_mb,))
         k = 0
@@ -566,11 +602,15 @@ class Runner:
             np.random.shuffle(ordering)
             order_dev = torch.from_numpy(ordering).to(self.device, non_blocking=True)
             for j in range(n_mb):
-                idx = order_dev[j * mb:(j + 1) * mb]
-                self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), mb, _p(mb_obs))
-                stats = step_fn(mb_obs, idx)
+                acc = self._Accumulator(self, net, n_micro)
+                for u in range(n_micro):
+                    idx = order_dev[j * mb + u * micro:j * mb + (u + 1) * micro]
+                    self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), micro, _p(mb_obs))
+                    stats = step_fn(mb_obs, idx, 1.0 / n_micro)
+                    acc.after_backward()
+                    self._call("ppo_colsum_f32", _p(stats), micro, n_stats, n_stats, _p(stat_rows[k]), 1 if u else 0)
+                acc.finish()
                 self.optimizer_step(optimizer, label)
-                self._call("ppo_colsum_f32", _p(stats), mb, n_stats, n_stats, _p(stat_rows[k]), 0)
                 norm_rows[k:k + 1].copy_(self._grad_norm, non_blocking=True)
                 k += 1
         self._phase_stats[label] = (stat_rows, norm_rows, mb)
@@ -586,16 +626,16 @@ class Runner:
         returns = None if self.dual else self.returns
         net.zero_untouched_grads()
         if self.action_dist == "discrete":
-            def step(mb_obs, idx):
+            def step(mb_obs, idx, loss_scale):
                 return net.ppo_minibatch(mb_obs, self.actions, self.log_pac, self.log_policy, self.norm_advantage,
                                          returns, eps_clip=self.ppo_epsilon, ent_coef=self.current_entropy_bonus,
-                                         vf_coef=args.ppo_vf_coef, loss_scale=1.0, index=idx)
+                                         vf_coef=args.ppo_vf_coef, loss_scale=loss_scale, index=idx)
         else:
             actions, log_pac = self.actions.view(B, self.n_actions), self.log_pac.view(B, self.n_actions)
 
-            def step(mb_obs, idx):
+            def step(mb_obs, idx, loss_scale):
                 return net.gaussian_minibatch(mb_obs, actions, log_pac, self.norm_advantage, returns,
-                                              eps_clip=self.ppo_epsilon, vf_coef=args.ppo_vf_coef, loss_scale=1.0,
+                                              eps_clip=self.ppo_epsilon, vf_coef=args.ppo_vf_coef, loss_scale=loss_scale,
                                               index=idx)
         self._run_epochs("policy", self.policy_optimizer, args.policy_opt.epochs, args.policy_opt.mini_batch_size,
                          step, 8)
@@ -616,10 +656,10 @@ class Runner:
         keep = 1.0 - args.tvf.horizon_dropout if self.tvf is not None else 1.0
         seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + 7919 * (self.rank + 1)
 
-        def step(mb_obs, idx):
+        def step(mb_obs, idx, loss_scale):
             off = self.tvf.next_dropout_offset(mb_obs.shape[0] * self.K) if keep < 1.0 else 0
             return net.value_minibatch(mb_obs, returns=returns, tvf_returns=tvf_returns, tvf_weights=weights,
-                                       vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=1.0, index=idx,
+                                       vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=loss_scale, index=idx,
                                        tvf_keep_prob=keep, dropout_seed=seed, dropout_offset=off)
         self._run_epochs("value", self.value_optimizer, args.value_opt.epochs, args.value_opt.mini_batch_size, step, 4)
 
@@ -672,10 +712,10 @@ class Runner:
         weights = self._tvf_weights_dev if batch["use_tvf"] else None
         net.zero_untouched_grads()
 
-        def step(mb_obs, idx):
+        def step(mb_obs, idx, loss_scale):
             return net.distil_minibatch(mb_obs, batch["distil_targets"], batch["old_policy"], beta=args.distil.beta,
-                                        use_tvf=batch["use_tvf"], weights=weights, gaussian=gaussian, loss_scale=1.0,
-                                        index=idx)
+                                        use_tvf=batch["use_tvf"], weights=weights, gaussian=gaussian,
+                                        loss_scale=loss_scale, index=idx)
         opt = self.policy_optimizer if args.distil.use_policy_opt else self.distil_optimizer
         self._run_epochs("distil", Optimizer(net, args.distil_opt, opt.state), args.distil_opt.epochs,
                          args.distil_opt.mini_batch_size, step, 4)
@@ -731,26 +771,56 @@ class Runner:
 
     def train_batch(self, batch_data, mini_batch_func, mini_batch_size, optimizer, label, epoch=None, hooks=None,
                     thinning=1.0, force_micro_batch_size=None, delta_threshold=None):
-        """One epoch of permutation minibatches through `mini_batch_func(data, loss_scale=...)`
-        (rl/rollout.py:2257-2407).  Micro-batch splitting is not needed with 288 GB of HBM: every minibatch
-        is one pass."""
+        """One epoch of permutation minibatches through `mini_batch_func(data, loss_scale=...)`, the reference's
+        dict-based API (rl/rollout.py:2257-2407): minibatches are split into micro-batches of `force_micro_batch_size`
+        (default min(--max_micro_batch_size, minibatch)) samples whose gradients accumulate under
+        loss_scale = 1 / micro_batches; `thinning` keeps that fraction of every micro-batch; `hooks`
+        ("after_micro_batch"(context), "after_mini_batch"(context) -> truthy stops before the optimiser step) are
+        called as the reference calls them; entries whose name starts with '*' are passed through whole.  Returns
+        {'mini_batches', 'outputs'[, 'did_break']}."""
+        if delta_threshold is not None and delta_threshold > 0:
+            raise Exception("Not supported")
         assert "prev_state" in batch_data, "Batches must contain 'prev_state' field of dims (B, *state_shape)"
         B = len(batch_data["prev_state"])
+        for k_, v in batch_data.items():
+            if not k_.startswith("*"):
+                assert len(v) == B, f"Batch input must all match in entry count. Expecting {B} but found {len(v)} on {k_}"
         mb = parallel.local_minibatch(mini_batch_size)
+        assert B % mb == 0
+        n_mb = B // mb
+        micro, n_micro = self._micro_batches(mb, force_micro_batch_size)
         ordering = np.arange(B)
         np.random.shuffle(ordering)
-        n = int((B // mb) * thinning) or 1
-        counter, last = 0, None
-        data = {k: (torch.as_tensor(v).to(self.device)) for k, v in batch_data.items() if not k.startswith("*")}
-        for j in range(n):
-            idx = torch.from_numpy(ordering[j * mb:(j + 1) * mb]).to(self.device)
+        data = {k_: (v.to(self.device) if isinstance(v, torch.Tensor) else torch.as_tensor(v).to(self.device))
+                for k_, v in batch_data.items()}
+        net = optimizer.net
+        outputs, context, counter = [], {}, 0
+        for j in range(n_mb):
             optimizer.zero_grad()
-            last = mini_batch_func({k: v[idx].contiguous() for k, v in data.items()}, loss_scale=1.0)
+            acc = self._Accumulator(self, net, n_micro)
+            for u in range(n_micro):
+                sample = ordering[counter * micro:(counter + 1) * micro]
+                counter += 1
+                if thinning < 1.0:
+                    sample = sample[:int(micro * thinning)]
+                idx = torch.from_numpy(sample).to(self.device)
+                micro_context = {"epoch": epoch, "mini_batch": j, "micro_batch": u, "is_first": j == 0,
+                                 "is_last": j == n_mb - 1}
+                micro_data = {"context": micro_context}
+                for k_, v in data.items():
+                    micro_data[k_] = v if k_.startswith("*") else v[idx].contiguous()
+                outputs.append(mini_batch_func(micro_data, loss_scale=1 / n_micro))
+                acc.after_backward()
+                if hooks is not None and "after_micro_batch" in hooks:
+                    hooks["after_micro_batch"](micro_context)
+            acc.finish()
+            context = {"mini_batches": j + 1, "outputs": outputs}
+            if hooks is not None and "after_mini_batch" in hooks:
+                if hooks["after_mini_batch"](context):
+                    context["did_break"] = True
+                    break
             self.optimizer_step(optimizer, label)
-            counter += 1
-        out = dict(last or {})
-        out["mini_batches"] = counter
-        return out
+        return context
 
     def fetch_stats(self):
         """ONE device->host copy per phase and iteration with everything the reference logs per minibatch
