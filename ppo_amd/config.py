@@ -87,7 +87,22 @@ class EnvConfig(_Group):  # rl/config.py:495-603
         ("max_repeated_actions", int, 100, "penalise repeating one action more than this many times (:513)"),
         ("repeated_action_penalty", float, 0.0, "the penalty (:514)"),
         ("warmup_period", int, 250, "random warm-up steps to desynchronise envs"),
-        ("timeout", int, 0, "episode step limit (0 = env default)"),
+        ("timeout", str, "auto", "episode step limit in agent steps: auto (atari 27000, procgen 1000, mujoco 1001, else off) or a number, 0 = off (:503)"),
+        ("repeat_action_probability", float, 0.0, "ALE sticky actions (:504)"),
+        ("noop_duration", int, 30, "maximum number of no-ops after a reset, 0 = none (:505)"),
+        ("per_step_termination_probability", float, 0.0, "probability that a step ends the episode (:506)"),
+        ("reward_clipping", str, "off", "[off|<R>|sqrt] (:507)"),
+        ("deferred_rewards", int, 0, "pay all rewards at this step (-1: at the end), 0 = off (:510)"),
+        ("full_action_space", bool, False, "ALE full action set (:517)"),
+        ("resolution", str, "nature", "[full|nature|half|muzero] (:520)"),
+        ("color_mode", str, "default", "[default|bw|rgb|yuv|hsv]; default = bw for atari, yuv for procgen (:521)"),
+        ("frame_stack", int, -1, "frames stacked, -1 = 4 for atari else 1 (:522)"),
+        ("frame_skip", int, -1, "simulator frames per agent step, -1 = 4 for atari else 1 (:523)"),
+        ("embed_state", bool, False, "draw a compressed state history onto the frame (:526)"),
+        ("atari_terminal_on_loss_of_life", bool, False, "(:529)"),
+        ("atari_rom_check", bool, True, "(:530; the ROM table is not part of this build: accepted and ignored)"),
+        ("procgen_difficulty", str, "hard", "[hard|easy] (:533)"),
+        ("zero_obs", bool, False, "blank observations (the reference's --debug_zero_obs)"),
         ("synthetic_done_prob", float, 0.01, "synthetic env: per-step termination probability"),
         ("synthetic_threads", int, 8, "synthetic env: host threads generating observations"),
         ("synthetic_actions", int, 0, "synthetic env: size of the action set (0 = 6, the Pong-shaped default)"),
@@ -200,6 +215,8 @@ class Config:
         self._ignored = []
 
     # ---- properties the reference derives (rl/config.py:885-901)
+    RESOLUTIONS = {"full": (210, 160), "procgen": (64, 64), "nature": (84, 84), "muzero": (96, 96), "half": (105, 80)}
+
     @property
     def batch_size(self):
         return self.n_steps * self.agents
@@ -291,8 +308,28 @@ class Config:
             raise ValueError("Invalid clip_mode.")
         if self.tvf.gamma is None:
             self.tvf.gamma = self.gamma
-        if self.env.timeout == 0:  # EnvConfig.auto, rl/config.py:579-600
-            self.env.timeout = {"atari": 27000, "procgen": 1000, "mujoco": 1001}.get(self.env.type, 0)
+        # EnvConfig.auto (rl/config.py:563-600)
+        if self.env.frame_skip in (None, -1):
+            self.env.frame_skip = 4 if self.env.type == "atari" else 1
+        if self.env.frame_stack in (None, -1):
+            self.env.frame_stack = 4 if self.env.type == "atari" else 1
+        if self.env.color_mode not in ("default", "bw", "rgb", "yuv", "hsv"):
+            raise ValueError(f"Invalid color mode {self.env.color_mode}")
+        if self.env.color_mode == "default":
+            self.env.color_mode = {"atari": "bw", "procgen": "yuv"}.get(self.env.type, "bw")
+        if self.env.timeout == "auto":
+            if self.env.type == "atari":
+                self.env.timeout = 27000
+            elif self.env.type == "procgen":
+                self.env.timeout = {"bigfish": 6000, "bossfight": 8000, "plunder": 4000}.get(self.env.name, 1000)
+            elif self.env.type == "mujoco":
+                self.env.timeout = (50 if self.env.name.lower() == "reacher" else 1000) + 1
+            else:
+                self.env.timeout = 0  # unlimited
+        else:
+            self.env.timeout = int(self.env.timeout)
+        if self.env.type in ("procgen", "mujoco") and (self.env.frame_stack != 1 or self.env.frame_skip != 1):
+            raise ValueError(f"Frame stacking / skipping not supported on {self.env.type} yet")  # (:555-560)
         if self.restore in ("True", "true", True):  # rl/config.py:810-812
             self.restore = "always"
         if self.restore not in ("always", "never", "auto"):

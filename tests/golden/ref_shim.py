@@ -34,9 +34,33 @@ def _install_mocks():
             sys.modules[n] = m
     gym = sys.modules["gym"]
 
-    class _Wrapper:  # placeholder base classes so `class X(gym.Wrapper)` resolves
+    class _Wrapper:  # placeholder base class so `class X(gym.Wrapper)` resolves; forwards like gym.Wrapper does
         def __init__(self, env=None, *a, **k):
             self.env = env
+
+        def __getattr__(self, name):  # only reached for attributes the wrapper itself lacks
+            if name.startswith("_") or name == "env":
+                raise AttributeError(name)
+            return getattr(self.__dict__["env"], name)
+
+        @property
+        def unwrapped(self):
+            env = self.__dict__.get("env")
+            return env.unwrapped if hasattr(env, "unwrapped") else env
+
+        def reset(self, **kwargs):
+            return self.env.reset(**kwargs)
+
+        def step(self, action):
+            return self.env.step(action)
+
+    class _Box:  # gym.spaces.Box / Discrete stand-ins: the reference reads .shape / .dtype / .n only
+        def __init__(self, low=None, high=None, shape=None, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape) if shape is not None else None, np.dtype(dtype)
+
+    class _Discrete:
+        def __init__(self, n):
+            self.n = int(n)
 
     class _VecEnv:
         def __init__(self, *a, **k):
@@ -55,6 +79,8 @@ def _install_mocks():
     gym.version = sys.modules["gym.version"]
     gym.version.VERSION = "0.21.0"
     gym.spaces = sys.modules["gym.spaces"]
+    gym.spaces.Box = _Box
+    gym.spaces.Discrete = _Discrete
 
 
 def load_reference(argv):
