@@ -383,7 +383,7 @@ class Runner:
         self._finished_lengths = [[] for _ in range(N)]
         env = self.vec_env
         parts = getattr(env, "parts", [env])
-        if all(hasattr(p, "step_arrays") for p in parts) and self.model.obs_norm is None:
+        if all(hasattr(p, "step_arrays") for p in parts):
             self._rollout_pipelined(parts)
         else:
             self._rollout_generic(env)
@@ -451,6 +451,49 @@ class Runner:
 
         tags = [f"i{i}" if P > 1 else "i" for i in range(P)]
         host_rows = [self._actions_host[bounds[i]:bounds[i + 1]] for i in range(P)]
+        norm = self.model.obs_norm
+        if norm is not None:
+            # Observation normalisation: the running statistics take in EVERY env's observation of step t before any
+            # group's forward of step t (rl/rollout.py:735-741), so the groups cannot run a step apart.  Per step: both
+            # uploads, one statistics update on the first group's stream, then the groups' policy steps on their own
+            # streams; the host steps group i while the GPU still runs the later groups' policy steps.  (The generic
+            # path synchronised the whole device once per env step and overlapped nothing.)
+            if not hasattr(self, "_norm_event"):
+                self._norm_event = torch.cuda.Event()
+            try:
+                for t in range(N + 1):
+                    torch.cuda.set_stream(copy_stream)
+                    for i in range(P):
+                        self.all_obs[t, bounds[i]:bounds[i + 1]].copy_(parts[i].obs_t, non_blocking=True)
+                    copy_events[0].record()
+                    torch.cuda.set_stream(streams[0])
+                    streams[0].wait_event(copy_events[0])
+                    if t < N:
+                        norm.update(self.all_obs[t])
+                    self._norm_event.record()
+                    for i in range(P):
+                        torch.cuda.set_stream(streams[i])
+                        streams[i].wait_event(self._norm_event)
+                        self._policy_step(t, bounds[i], bounds[i + 1], tag=tags[i])
+                        if t < N:
+                            host_rows[i].copy_(self.actions[t, bounds[i]:bounds[i + 1]], non_blocking=True)
+                            events[i].record()
+                    if t < N:
+                        for i in range(P):
+                            step_envs(i, t)
+                        # the next step's upload overwrites nothing the GPU still reads, but its statistics update
+                        # must follow this step's forwards (they read mu / std): order stream 0 behind the others
+                        for s_ in streams[1:]:
+                            streams[0].wait_stream(s_)
+            finally:
+                torch.cuda.set_stream(main)
+            for s_ in streams:
+                if s_ is not main:
+                    main.wait_stream(s_)
+            main.wait_stream(copy_stream)
+            self.time = self.all_time[N].copy()
+            self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
+            return
         try:
             for t in range(N + 1):
                 for i in range(P):

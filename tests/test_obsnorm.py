@@ -198,3 +198,49 @@ def test_runner_with_normalisation_trains_and_checkpoints(tmp_path):
         assert torch.equal(model.forward(r.all_obs[0], output="policy")["log_policy"], out_before)
     finally:
         r.vec_env.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_rollout_with_normalisation_equals_the_generic_path():
+    """With array-stepping envs the rollout keeps its per-group streams and host / GPU overlap under observation
+    normalisation too: statistics from every env's step-t observation first, then the groups' forwards.  Same bytes as
+    the one-group, one-sync-per-step path the reference's order was first built on."""
+    from ppo_amd import logger, models, rollout
+    from ppo_amd.config import args
+    from ppo_amd.vec_env import SplitVecEnv, SyntheticVecEnv
+
+    class GymOnly:  # hides step_arrays: the Runner takes the generic path
+        def __init__(self, env):
+            self.env, self.num_envs = env, env.num_envs
+
+        def reset(self):
+            return self.env.reset()
+
+        def step(self, a):
+            return self.env.step(a)
+
+    args.setup(["--agents=32", "--n_steps=8", "--model_architecture=single", "--model_encoder=impala", "--env_type=synthetic",
+                "--env_embed_time=False", "--seed=3", "--device=cuda", "--disable_logging=True",
+                "--observation_normalization=True"])
+    outs = []
+    for mode in ("generic", "pipelined"):
+        torch.manual_seed(3)
+        model = models.TVFModel("impala", input_dims=(4, 84, 84), actions=6, device="cuda", architecture="single",
+                                hidden_units=256, head_scale=0.1, head_bias=True, observation_normalization=True,
+                                norm_eps=args.observation_normalization_epsilon)
+        r = rollout.Runner(model, logger.Logger(quiet=True))
+        if mode == "generic":
+            r.vec_env = GymOnly(SyntheticVecEnv(32, seed=3, p_done=0.05, threads=2))
+        else:
+            r.vec_env = SplitVecEnv([SyntheticVecEnv(16, seed=3, p_done=0.05, env_offset=16 * i, threads=2) for i in range(2)])
+        r.reset()
+        r.generate_rollout()
+        r.generate_rollout()
+        torch.cuda.synchronize()
+        assert abs(model.obs_norm.count - (1e-4 + 2 * 8 * 32)) < 1e-9
+        outs.append([x.cpu().clone() for x in (r.all_obs, r.actions, r.log_policy, r.value, r.ext_rewards, r.terminals,
+                                               model.obs_norm.mean, model.obs_norm.var, model.obs_norm.mu, model.obs_norm.std)]
+                    + [torch.from_numpy(r.all_time.copy())])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][5].any() and len(torch.unique(outs[0][1])) > 1

@@ -298,7 +298,7 @@ def test_tvf_trimming_and_horizon_dropout_through_the_runner():
     assert np.isfinite(stats["loss_tvf"]) and stats["loss_tvf"] > 0 and r.tvf._dropout_calls > 0
 
 
-def _fake_atari_env(seed):
+def _fake_atari_env(seed, cfg):
     """Atari wrapper stack (ppo_amd.atari.make, the reference's rl/atari.py:119-230 order) over the scripted simulator."""
     import os
     import sys
@@ -307,7 +307,8 @@ def _fake_atari_env(seed):
         sys.path.insert(0, golden)
     import fake_envs
     from ppo_amd import atari
-    return atari.make("FakeGame", seed=seed, base_env=fake_envs.FakeAtari())
+    # cfg: the parsed flags travel with the constructor — env workers are spawned, their own `args` is unparsed
+    return atari.make("FakeGame", seed=seed, args=cfg, base_env=fake_envs.FakeAtari())
 
 
 def test_atari_wrapper_stack_through_the_process_pool_and_runner():
@@ -317,7 +318,7 @@ def test_atari_wrapper_stack_through_the_process_pool_and_runner():
     action) in worker processes, the shared pinned observation block, rms reward normalisation, the IMPALA net at
     5 x 84 x 84."""
     import functools
-    args.setup(["--agents=8", "--n_steps=16", "--model_architecture=single", "--model_encoder=impala", "--env_type=atari",
+    args.setup(["--agents=8", "--n_steps=32", "--model_architecture=single", "--model_encoder=impala", "--env_type=atari",
                 "--env_name=FakeGame", "--env_timeout=40", "--env_noop_duration=4", "--seed=5", "--device=cuda",
                 "--policy_opt_mini_batch_size=64", "--policy_opt_epochs=1", "--workers=4", "--disable_logging=True"])
     assert (args.env.frame_skip, args.env.frame_stack, args.env.color_mode) == (4, 4, "bw")
@@ -328,7 +329,7 @@ def test_atari_wrapper_stack_through_the_process_pool_and_runner():
     model = models.TVFModel("impala", input_dims=shape, actions=nA, device="cuda", architecture="single",
                             hidden_units=256, head_scale=0.1, head_bias=True)
     r = rollout.Runner(model, logger.Logger(quiet=True))
-    r.vec_env = envs.create_envs_classic(env_fns=[functools.partial(_fake_atari_env, 100 + 997 * i) for i in range(8)])
+    r.vec_env = envs.create_envs_classic(env_fns=[functools.partial(_fake_atari_env, 100 + 997 * i, args) for i in range(8)])
     try:
         r.reset()
         assert r.obs.shape == (8, 5, 84, 84) and r.obs.dtype == np.uint8
@@ -338,13 +339,13 @@ def test_atari_wrapper_stack_through_the_process_pool_and_runner():
             r.train()
         torch.cuda.synchronize()
         obs = r.all_obs.cpu().numpy()
-        assert obs.shape == (17, 8, 5, 84, 84) and obs[..., :4, :, :].max() > 0
+        assert obs.shape == (33, 8, 5, 84, 84) and obs[..., :4, :, :].max() > 0
         # the time channel: uint8(255 * steps / timeout) of the state, constant over the frame, 0 right after a reset
         tc = obs[:, :, 4]
         assert (tc == tc[:, :, :1, :1]).all() and tc.max() > 0
-        assert np.array_equal(np.unique(tc[1:][r.terminals.cpu().numpy()[:16]]), [0])
+        assert np.array_equal(np.unique(tc[1:][r.terminals.cpu().numpy()]), [0])
         # episodes end by the 40-step time limit (or the simulator), rewards are normalised and finite
         assert int(r.terminals.sum()) >= 2 and r.all_time.max() <= 40
-        assert torch.isfinite(r.ext_rewards).all() and torch.isfinite(r.net.flat).all() and r.net._adam_step == 4
+        assert torch.isfinite(r.ext_rewards).all() and torch.isfinite(r.net.flat).all() and r.net._adam_step == 8
     finally:
         r.vec_env.close()
