@@ -525,7 +525,11 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
 #ifndef PPO_TUNE_WGRAD_BIGSLABS
     if ((size_t)COUT * C::JP * sizeof(float) > 16 * 1024) per_cu = 1;  // big slabs: keep the reduce traffic down
 #endif
-    int grid = 256 * per_cu;
+    // `count` problems share the chip (blockIdx.y): each gets 1 / count of the resident workgroups, so a batched launch
+    // is ONE wave of workgroups, each walking count x as many items — a quarter of the slabs to write and reduce
+    // (4 x 256 slabs of 39 KB were 1.6-2.3 x the tensors themselves for the 21x21 / 11x11 layers) and a quarter of the
+    // per-workgroup prologue / K-group fold
+    int grid = (256 * per_cu + count - 1) / count;
     if (grid > kWgradMaxSlabs) grid = kWgradMaxSlabs;
     if (grid > n_items) grid = n_items;
     const size_t need = (size_t)grid * COUT * C::JP * sizeof(float);

@@ -337,5 +337,20 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
             assert torch.equal(v, acts_b[k]), (B, k)
         b.ppo_minibatch(x, actions, pac, logp, adv, ret)
         torch.cuda.synchronize()
-        assert torch.equal(a.grad, b.grad) and float(a.grad.abs().sum()) > 0, B
+        # Bit-identical everywhere except the block convolutions' weight / bias gradients: a batched launch gives each
+        # problem a quarter of the workgroups (one wave of workgroups for the whole batch), so its slabs partition the
+        # (image, band) items differently from a per-convolution launch — the same products in another summation
+        # order.  Both orders are fixed (deterministic); they agree to float32 round-off.
+        assert float(a.grad.abs().sum()) > 0, B
+        for name in a.grads:
+            ga, gb = a.grads[name], b.grads[name]
+            if ".blocks." in name:
+                assert float((ga - gb).abs().max()) <= 2e-6 * max(float(gb.abs().max()), 1e-30), (B, name)
+            else:
+                assert torch.equal(ga, gb), (B, name)
+        a.ppo_minibatch(x, actions, pac, logp, adv, ret)
+        again = a.grad.clone()
+        a.ppo_minibatch(x, actions, pac, logp, adv, ret)
+        torch.cuda.synchronize()
+        assert torch.equal(a.grad, again), "the batched weight-gradient launch is not deterministic"
         assert {("bwd", 1), ("full_bwd", 2)} <= set(a._tail_ptrs), "the fused backward did not engage"

@@ -36,7 +36,7 @@ for key in sorted(set(fetch) & set(write)):
                  "WRITE_SIZE_KiB": sum(w) / len(w),
                  "hbm_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024})
 rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
-how = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 1 --warmup 0` (tools/pmc_bench.sh), "
+how = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --n-steps 8 --steps 1 --warmup 1` (tools/pmc_bench.sh: the bench iteration with a short rollout, every training kernel at its minibatch geometry), "
        "average over the training-minibatch launches, (2 x FETCH + WRITE) KiB")
 out = {"tag": tag, "rows": rows[:60]}
 for short in ("stack_full_kernel", "stack_tail_kernel", "conv3x3_kernel"):
