@@ -718,11 +718,20 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
             stage_band_flat<CIN, C::CINP, H, W, C::ROWS, C::PLANE, C::G, IN_MODE, kWaves>(in_, img, y0, dst, tid);
     };
     if (DMA && (int)blockIdx.x < n_items) stage(blockIdx.x, smem);
-    // uint8 observations: the next item's band waits in registers while this item computes
+    // uint8 observations: the next item's band waits in registers while this item computes (four pixels per
+    // register where the row length allows dword loads)
+    constexpr bool U8X4 = !DMA && IN_MODE == IN_U8 && W % 4 == 0;
     using FM = FlatMap<C::CINP, W, C::ROWS, kWaves>;
-    uint32_t raw[DMA ? 1 : FM::Q];
+    using FM4 = FlatU8Map<CIN, (U8X4 ? W : 4), C::ROWS, kThreads>;
+    uint32_t raw[DMA ? 1 : (U8X4 ? FM4::Q : FM::Q)];
+    if constexpr (U8X4) {  // padded channels and the guards are never written by the dword path
+        zero_lds<C::NBUF * C::LDS_IN, kThreads>(smem, tid);
+        __syncthreads();
+    }
     auto prefetch = [&](int item) {
-        if constexpr (!DMA)
+        if constexpr (U8X4)
+            band_u8x4_load<CIN, H, W, C::ROWS, kThreads>(in_, item / C::NBANDS, 2 * (item % C::NBANDS) * PR - 1, tid, raw);
+        else if constexpr (!DMA)
             band_flat_load<CIN, C::CINP, H, W, C::ROWS, IN_MODE, kWaves>(in_, item / C::NBANDS,
                                                                          2 * (item % C::NBANDS) * PR - 1, tid, raw);
     };
@@ -734,15 +743,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int img = item / C::NBANDS;
         const int yo0 = (item % C::NBANDS) * PR;
+        PPO_STAMP(t_top)
         if constexpr (DMA) {
             __syncthreads();  // band landed; previous item's pooling reads of s_out are done
             if (item + (int)gridDim.x < n_items) stage(item + gridDim.x, smem + (buf ^ 1) * C::LDS_IN);
         } else {
             __syncthreads();  // previous item's readers are done with the band and s_out
-            band_flat_store<C::CINP, W, C::ROWS, C::PLANE, C::G, IN_MODE, kWaves>(raw, smem, tid);
+            if constexpr (U8X4) band_u8x4_store<CIN, W, C::ROWS, C::PLANE, C::G, kThreads>(raw, smem, tid);
+            else band_flat_store<C::CINP, W, C::ROWS, C::PLANE, C::G, IN_MODE, kWaves>(raw, smem, tid);
             if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
             __syncthreads();
         }
+        PPO_STAMP(t_staged)
         // ---- convolution rows -> s_out
 #pragma unroll 1
         for (int q = 0; q < NGW; ++q) {
@@ -801,14 +813,68 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
                         }
                 }
         }
+        PPO_STAMP(t_conv)
         __syncthreads();  // all convolution rows of the band are in s_out
+        PPO_STAMP(t_bar2)
         // ---- pool from LDS: ties to the first tap in row-major window order, padding excluded, NaN propagates
         // (same rule as maxpool_fwd_kernel / F.max_pool2d)
         // A wave pass covers RPW pooled rows of WO outputs (lane -> (row in pass, xo)); rows are (co, pr) pairs
         // with pr fastest, so the only divisions are by compile-time constants.
+        const int pr_n = min(PR, C::HO - yo0);
+        if constexpr (C::WO % 2 == 0 && W % 4 == 0 && C::OPLANE % 4 == 0) {
+            // Even pooled width: a thread produces TWO neighbouring outputs (xo = 2 xp, 2 xp + 1).  Their windows cover
+            // columns 4 xp - 1 .. 4 xp + 3 of three rows: one 16-byte LDS read + one 4-byte read per row (15 values for
+            // 18 taps) instead of 18 strided 4-byte reads, and the pair leaves as one 8-byte store (+ one 2-byte argmax
+            // store).  Tasks are the flat (channel, pooled row, pair) index, so every lane works: the row-per-wave form
+            // left a third of the lanes idle at 42 outputs per row and spent 58 % of an item here (stamps).
+            constexpr int XP = C::WO / 2, NTASK = COUT * PR * XP;
+            for (int task = tid; task < NTASK; task += kThreads) {
+                const int co = task / (PR * XP), rem = task % (PR * XP);
+                const int pr = rem / XP, xp = rem % XP;
+                if (pr >= pr_n) continue;
+                const int yo = yo0 + pr;
+                const float *row0 = s_out + co * C::OPLANE + 2 * pr * W + 4 * xp;  // column 4 xp of conv row 2 pr
+                float v[3][5];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float4 q = *reinterpret_cast<const float4 *>(row0 + ky * W);
+                    v[ky][0] = xp > 0 ? row0[ky * W - 1] : 0.f;
+                    v[ky][1] = q.x, v[ky][2] = q.y, v[ky][3] = q.z, v[ky][4] = q.w;
+                }
+                float best[2];
+                int tap[2];
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const int xo = 2 * xp + o;
+                    float b = -INFINITY;
+                    int bt = 0;
+                    bool found = false;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const bool row_ok = (ky == 0) ? yo > 0 : (ky == 1 ? true : 2 * yo + 1 < H);
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const bool col_ok = (kx == 0) ? xo > 0 : (kx == 1 ? true : 2 * xo + 1 < W);
+                            if (row_ok && col_ok) {
+                                const float x = v[ky][2 * o + kx];
+                                if (!found || x > b || x != x) {
+                                    b = x;
+                                    bt = ky * 3 + kx;
+                                    found = true;
+                                }
+                            }
+                        }
+                    }
+                    best[o] = b;
+                    tap[o] = bt;
+                }
+                const size_t oi = ((size_t)(img * COUT + co) * C::HO + yo) * C::WO + 2 * xp;
+                *reinterpret_cast<float2 *>(out + oi) = make_float2(best[0], best[1]);
+                if (argmax) *reinterpret_cast<unsigned short *>(argmax + oi) = (unsigned short)(tap[0] | (tap[1] << 8));
+            }
+        } else {
         constexpr int RPW = 64 / C::WO;
         const int sub = lane / C::WO, xo = lane % C::WO;
-        const int pr_n = min(PR, C::HO - yo0);
         for (int u0 = wave * RPW; u0 < COUT * PR; u0 += kWaves * RPW) {
             const int u = u0 + sub;
             const int co = u / PR, pr = u % PR;
@@ -839,6 +905,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
                 if (argmax) argmax[oi] = (uint8_t)best_tap;
             }
         }
+        }
+        PPO_STAMP(t_end)
+        PPO_STAMP_ADD(0, t_staged, t_top)   // barrier(s) + staging
+        PPO_STAMP_ADD(1, t_conv, t_staged)  // convolution groups -> s_out
+        PPO_STAMP_ADD(2, t_bar2, t_conv)    // barrier before pooling
+        PPO_STAMP_ADD(3, t_end, t_bar2)     // pooling + stores
+        PPO_STAMP_ADD(4, t_end, t_top)      // whole item
+        if (lane == 0) { PPO_STAMP_ADD(5, 1ull, 0ull) }
         if constexpr (DMA) buf ^= 1;
     }
 }
@@ -893,7 +967,7 @@ int dispatch_conv_pool(int cin, int cout, int h, int w_, const void *in, const f
 #define PPO_CP_MT84 5
 #endif
 #ifndef PPO_CP_PR42
-#define PPO_CP_PR42 3   // 7 rows x 42 = 19 tiles -> 7 groups of 3
+#define PPO_CP_PR42 4   // 9 rows x 42 = 24 tiles -> 8 groups of 3: every wave busy (PR 3: 19 tiles -> 7 groups, 75.7 vs 73.3 us)
 #define PPO_CP_MT42 3
 #endif
 #ifndef PPO_CP_PR21

@@ -55,7 +55,7 @@ template <int IN_MODE, int NBANDS>
 constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : PPO_TUNE_WGRAD_NBUF; }
 // contiguous-run band layout (16-byte LDS-DMA) wherever both bands arrive by DMA
 template <int IN_MODE, bool DY_POOLED>
-constexpr bool wgrad_run() { return IN_MODE != IN_U8 && !DY_POOLED; }
+constexpr bool wgrad_run() { return true; }  // (the halo-column layout remains for reference behind RUN = false)
 constexpr int kWgradWaves = 8;
 
 template <int CIN, int COUT, int H, int W, int TR, int NBUF_, bool RUN_>
@@ -88,7 +88,9 @@ struct WgradCfg {
     static constexpr int STEPS = RUN ? (TR * W + 3) / 4 : TR * (W / 4);
     // RUN: step s reads dy[4s .. 4s+3] and x[4s + G - 1 + ky*W + kx + 0..3]
     static constexpr int XRUN = 4 * STEPS + 2 * W + 2 * G > ROWS * W + 2 * G ? 4 * STEPS + 2 * W + 2 * G : ROWS * W + 2 * G;
-    static constexpr int XPLANE = pad_mod32(RUN ? XRUN : ROWS * PWX, 2);
+    // plane stride 2 (mod 32) banks: 16 channels x 2 adjacent pixels conflict-free; the observation convolution
+    // (<= 8 channels, staged four pixels per lane with 16-byte LDS stores) takes 4 (mod 32) for the alignment
+    static constexpr int XPLANE = pad_mod32(RUN ? XRUN : ROWS * PWX, (RUN && CINP <= 8) ? 4 : 2);
     static constexpr int DPLANE = pad_mod32(RUN ? 4 * STEPS : TR * PWD, 2);
     static constexpr int LDS_X = (CINP + 2) * XPLANE;  // + ones plane (BIAS_IN_TILE) + zeros plane
     static constexpr int LDS_D = COUT * DPLANE;
@@ -245,9 +247,21 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
         if constexpr (C::RUN) {
-            stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
-            // the same routine for the TR rows y0 .. y0 + TR - 1 of dy: its first row is (y0 + 1) - 1, no guard
-            stage_band_chunk_dma<COUT, H, W, TR, C::DPLANE, 0, kWgradWaves>(dy, img, y0 + 1, bd, tid);
+            if constexpr (IN_MODE == IN_U8) {
+                // uint8 observations: four pixels per lane (dword load, exact x / 255, 16-byte LDS store)
+                uint32_t raw[FlatU8Map<CIN, W, C::ROWS, kWgradWaves * 64>::Q];
+                band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, img, y0, tid, raw);
+                band_u8x4_store<CIN, W, C::ROWS, C::XPLANE, C::G, kWgradWaves * 64>(raw, bx, tid);
+            } else {
+                stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
+            }
+            if constexpr (DY_POOLED) {
+                static_assert(C::LDS_X % 2 == 0 && C::LDS_BUF % 2 == 0 && C::DPLANE % 2 == 0, "stage_dy_pooled stores float2 pairs");
+                stage_dy_pooled<COUT, H, W, TR, C::PWD, C::DPLANE, kWgradWaves>(dy, batch.argmax, img, y0, bd, tid);
+            } else {
+                // the same routine for the TR rows y0 .. y0 + TR - 1 of dy: its first row is (y0 + 1) - 1, no guard
+                stage_band_chunk_dma<COUT, H, W, TR, C::DPLANE, 0, kWgradWaves>(dy, img, y0 + 1, bd, tid);
+            }
             return;
         } else if constexpr (IN_MODE == IN_U8)
             stage_band<CIN, C::CINP, H, W, C::ROWS, C::PWX, C::XPLANE, 1, IN_MODE, kWgradWaves>(in_, img, y0, bx, tid);

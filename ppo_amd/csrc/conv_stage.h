@@ -18,6 +18,17 @@ namespace ppo {
 
 enum { IN_NONE = 0, IN_RELU = 1, IN_U8 = 2 };
 
+// uint8 observation -> x / 255 (rl/models.py:842-848: x.float() / 255), bit for bit the IEEE quotient for every one of
+// the 256 inputs, as a multiply and two fused multiply-adds instead of the ~10-instruction division sequence:
+//   q = x * (1/255);  q += (x - 255 q) * (1/255)     (one Newton correction of the rounded reciprocal product;
+// checked exhaustively on the host, tests/test_host_cpu.py, and against torch on the device, tests/test_conv_gpu.py)
+__device__ __forceinline__ float u8_unit(float x)
+{
+    constexpr float r = 1.0f / 255.0f;
+    const float q = x * r;
+    return fmaf(fmaf(q, -255.0f, x), r, q);
+}
+
 // s_dst[c * PLANE + r * PW + col] for c < CP, r < ROWS, col < PW holds
 //   f(src[img][c][y0 + r - HALO][col - HALO])   (0 outside the image or for c >= C)
 template <int C, int CP, int H, int W, int ROWS, int PW, int PLANE, int HALO, int IN_MODE, int NWAVES>
@@ -63,7 +74,7 @@ __device__ __forceinline__ void stage_band(const void *__restrict__ src_, int im
         for (int u = 0; u < U; ++u) {
             if (off[u] >= 0) {
                 float x = v[u];
-                if (IN_MODE == IN_U8) x = x / 255.0f;
+                if (IN_MODE == IN_U8) x = u8_unit(x);
                 if (IN_MODE == IN_RELU) x = fmaxf(x, 0.f);
                 s_dst[off[u]] = x;
             }
@@ -238,7 +249,7 @@ __device__ __forceinline__ void stage_band_flat(const void *__restrict__ src_, i
         for (int u = 0; u < U; ++u) {
             if (off[u] >= 0) {
                 float x = v[u];
-                if (IN_MODE == IN_U8) x = x / 255.0f;
+                if (IN_MODE == IN_U8) x = u8_unit(x);
                 if (IN_MODE == IN_RELU) x = fmaxf(x, 0.f);
                 s_dst[off[u]] = x;
             }
@@ -301,10 +312,60 @@ __device__ __forceinline__ void band_flat_store(const uint32_t (&raw)[FlatMap<CP
         const int col = col0 + 64 * pass;
         if (r < ROWS && col < W) {
             float x;
-            if (IN_MODE == IN_U8) x = (float)raw[q] / 255.0f;
+            if (IN_MODE == IN_U8) x = u8_unit((float)raw[q]);
             else x = __uint_as_float(raw[q]);
             if (IN_MODE == IN_RELU) x = fmaxf(x, 0.f);
             s_dst[c * PLANE + G + r * W + col] = x;
+        }
+    }
+}
+
+// uint8 observations, FOUR pixels per lane (W % 4 == 0): in the flat layout a channel's band is one contiguous run of
+// ROWS * W bytes in global memory and of as many floats in LDS, so thread t of the workgroup takes dword t (then
+// t + threads, ...) of the [channel][run] index space: one 4-byte load, four v_cvt_f32_ubyteN + u8_unit, one 16-byte
+// LDS store.  The per-pixel form issued one byte load and one 4-byte LDS store per pixel (16 load slots per thread for
+// the 84x84 band, a third of them masked off) — the first layer is bound by instruction issue, not by MFMAs (K = 36).
+// Two phases like band_flat_load / band_flat_store, so the next item's loads fly during this item's compute.
+template <int C, int W, int ROWS, int NTHREADS>
+struct FlatU8Map {
+    static_assert(W % 4 == 0, "a dword must not straddle two rows");
+    static constexpr int DW = ROWS * W / 4;                           // dwords per channel run
+    static constexpr int Q = (C * DW + NTHREADS - 1) / NTHREADS;      // dwords (registers) per thread
+};
+
+template <int C, int H, int W, int ROWS, int NTHREADS>
+__device__ __forceinline__ void band_u8x4_load(const void *__restrict__ src_, int img, int y0, int tid,
+                                               uint32_t (&raw)[FlatU8Map<C, W, ROWS, NTHREADS>::Q])
+{
+    using M = FlatU8Map<C, W, ROWS, NTHREADS>;
+    const uint8_t *src = static_cast<const uint8_t *>(src_);
+#pragma unroll
+    for (int q = 0; q < M::Q; ++q) {
+        const int idx = tid + q * NTHREADS;
+        const int c = idx / M::DW, d = idx % M::DW;
+        const int r = (4 * d) / W, col = (4 * d) % W;
+        const int gy = y0 + r - 1;
+        raw[q] = 0;  // rows outside the image read as zeros
+        if (idx < C * M::DW && gy >= 0 && gy < H)
+            raw[q] = *reinterpret_cast<const uint32_t *>(src + ((size_t)(img * C + c) * H + gy) * W + col);
+    }
+}
+
+template <int C, int W, int ROWS, int PLANE, int G, int NTHREADS>
+__device__ __forceinline__ void band_u8x4_store(const uint32_t (&raw)[FlatU8Map<C, W, ROWS, NTHREADS>::Q],
+                                                float *__restrict__ s_dst, int tid)
+{
+    using M = FlatU8Map<C, W, ROWS, NTHREADS>;
+    static_assert(PLANE % 4 == 0 && G % 4 == 0, "16-byte aligned LDS stores");
+#pragma unroll
+    for (int q = 0; q < M::Q; ++q) {
+        const int idx = tid + q * NTHREADS;
+        if (idx < C * M::DW) {
+            const int c = idx / M::DW, d = idx % M::DW;
+            const uint32_t v = raw[q];
+            *reinterpret_cast<float4 *>(s_dst + c * PLANE + G + 4 * d) =
+                make_float4(u8_unit((float)(v & 0xffu)), u8_unit((float)((v >> 8) & 0xffu)),
+                            u8_unit((float)((v >> 16) & 0xffu)), u8_unit((float)(v >> 24)));
         }
     }
 }

@@ -197,3 +197,35 @@ def test_packed_weights_give_the_raw_weight_results_bitwise(cin, cout, hw):
         _lib.check(lib.ppo_conv3x3_pool_forward_packed_f32(_p(x), 0, _p(pf), _p(b), _p(p2), _p(i2), n, cin, cout, hw, hw,
                                                            _lib.current_stream()), "pool packed")
         assert torch.equal(p1, p2) and torch.equal(i1, i2)
+
+
+@pytest.mark.parametrize("cin,hw", [(4, 84), (3, 64)])
+def test_uint8_scaling_is_the_exact_quotient_for_all_256_values(cin, hw):
+    """x / 255 on load (rl/models.py:842-848) is computed as a multiply and two FMAs (csrc/conv_stage.h u8_unit); with
+    a filter that copies channel 0's centre tap every output is fl(x / 255), so all 256 inputs are checked bit for
+    bit against torch's division — through the plain first convolution (per-pixel staging) and through the fused
+    convolution + max-pool kernel (four-pixels-per-lane staging; an image of 2x2 constant blocks pools to itself)."""
+    dev = torch.device("cuda")
+    lib = _lib.load()
+    w = torch.zeros(16, cin, 3, 3, device=dev)
+    w[0, 0, 1, 1] = 1.0
+    vals = torch.arange(256, dtype=torch.uint8, device=dev)
+    x = torch.zeros((2, cin, hw, hw), dtype=torch.uint8, device=dev)
+    x[0, 0].view(-1)[:256] = vals
+    x[1, 0].view(-1)[-256:] = vals.flip(0)
+    out = conv_fwd(x, w, None, None, _lib.PPO_IN_U8)
+    # the quotient is taken on the CPU: torch's GPU kernel for tensor / scalar multiplies by fl(1 / 255) instead, which
+    # differs from the IEEE quotient in the last bit for 126 of the 256 inputs; the fixtures (and the reference's
+    # --device=cpu path) divide
+    assert torch.equal(out[:, 0].cpu(), x[:, 0].cpu().float() / 255.0)
+    assert float(out[:, 1:].abs().max()) == 0.0
+    # pooled: value v fills the 2x2 block b = v of channel 0 (blocks in row-major order), so pooled[b] = v / 255
+    xb = torch.zeros((1, cin, hw, hw), dtype=torch.uint8, device=dev)
+    blocks = torch.arange((hw // 2) ** 2, device=dev) % 256
+    xb[0, 0] = blocks.to(torch.uint8).view(hw // 2, hw // 2).repeat_interleave(2, 0).repeat_interleave(2, 1)
+    pooled = torch.empty((1, 16, hw // 2, hw // 2), device=dev)
+    rc = lib.ppo_conv3x3_pool_forward_f32(_p(xb), _lib.PPO_IN_U8, _p(w), None, _p(pooled), None, 1, cin, 16, hw, hw,
+                                          _lib.current_stream())
+    _lib.check(rc, "ppo_conv3x3_pool_forward_f32")
+    want = F.max_pool2d(xb[:, :1].cpu().float() / 255.0, 3, 2, 1)
+    assert torch.equal(pooled[:, :1].cpu(), want)

@@ -285,3 +285,19 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     # N = 1 takes no launcher and no process group
     r = _bench("--gpus", "1", "--rendezvous-only")
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
+
+
+def test_u8_unit_recipe_is_the_exact_quotient():
+    """csrc/conv_stage.h u8_unit: q = x * fl(1/255); q = fma(fma(q, -255, x), fl(1/255), q) equals fl(x / 255) for every
+    uint8 x.  float32 FMAs are emulated exactly in float64 (products and sums of these magnitudes are exact there)."""
+    x = np.arange(256, dtype=np.float32)
+    want = x / np.float32(255.0)
+    r = np.float32(1.0) / np.float32(255.0)
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+
+    q = (x * r).astype(np.float32)
+    assert int((q != want).sum()) > 0, "the bare reciprocal product is NOT exact: the correction is needed"
+    got = fma(fma(q, np.float32(-255.0), x), r, q)
+    assert np.array_equal(got, want)

@@ -49,6 +49,8 @@ int main(int argc, char **argv)
     CK(hipMalloc(&db, 32 * 4));
     const size_t ws_bytes = ppo_conv3x3_wgrad_workspace_bytes(32, 32);
     CK(hipMalloc(&ws, ws_bytes));
+    float *dw_big;  // argmax scratch of the conv + pool runs
+    CK(hipMalloc(&dw_big, max_act));
     fill_kernel<<<2048, 256>>>(in, max_act, 1);
     fill_kernel<<<2048, 256>>>(out, max_act, 2);
     fill_kernel<<<64, 256>>>(w, 32 * 32 * 9, 3);
@@ -60,14 +62,18 @@ int main(int argc, char **argv)
     printf("%-34s %10s %10s\n", "kernel (batch 256)", "us", "TFLOP/s");
     for (const Geo &g : geos) {
         const double flops = 2.0 * 9 * g.cin * g.cout * g.hw * g.hw * B;
-        for (int which = 0; which < 3; ++which) {
+        for (int which = 0; which < 4; ++which) {
             if (which == 1 && g.cin <= 5) continue;  // no backward-data for the observation conv
+            if (which == 3 && !(g.hw == 84 || (g.hw == 42 && g.cout == 32) )) continue;  // conv + max-pool: stack-first layers
             auto go = [&]() {
                 int rc = 0;
                 if (which == 0)
                     rc = ppo_conv3x3_forward_f32(in, g.in_mode, w, bias, nullptr, out, B, g.cin, g.cout, g.hw, g.hw, nullptr);
                 else if (which == 1)
                     rc = ppo_conv3x3_backward_data_f32(out, w, in, nullptr, in, B, g.cin, g.cout, g.hw, g.hw, nullptr);
+                else if (which == 3)
+                    rc = ppo_conv3x3_pool_forward_f32(in, g.in_mode, w, bias, out, (uint8_t *)dw_big, B, g.cin, g.cout, g.hw, g.hw,
+                                                      nullptr);
                 else
                     rc = ppo_conv3x3_backward_weight_f32(in, g.in_mode, out, dw, db, ws, ws_bytes, B, g.cin, g.cout,
                                                          g.hw, g.hw, 0, nullptr);
@@ -86,11 +92,11 @@ int main(int argc, char **argv)
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / reps;
             char name[64];
-            snprintf(name, sizeof name, "%s %d->%d @%dx%d", which == 0 ? "fwd  " : (which == 1 ? "bwd-d" : "wgrad"),
+            snprintf(name, sizeof name, "%s %d->%d @%dx%d", which == 0 ? "fwd  " : (which == 1 ? "bwd-d" : (which == 2 ? "wgrad" : "fwd+p")),
                      g.cin, g.cout, g.hw, g.hw);
             printf("%-34s %10.1f %10.1f\n", name, us, flops / us / 1e6);
 #ifdef PPO_TUNE_STAMPS
-            if (which <= 2) {
+            if (which <= 3) {
                 static std::vector<unsigned long long> all(8 * 8 * 1024), zeros(8 * 8 * 1024, 0);
                 CK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(ppo::ppo_tune_stamps), all.size() * 8));
                 CK(hipMemcpyToSymbol(HIP_SYMBOL(ppo::ppo_tune_stamps), zeros.data(), zeros.size() * 8));
