@@ -299,11 +299,44 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
             buf ^= 1;
         }
     } else {
+        // Register-staged operands (uint8 observations, the pooled gradient's gather) are fetched for the NEXT item
+        // before this item's K loop and written to LDS after it, so their load latency hides under the MFMAs (the
+        // single-buffered loop exposed it: staging was 65 % of an item).  DMA-staged operands keep the plain order.
+        constexpr bool PRE_X = C::RUN && IN_MODE == IN_U8, PRE_D = C::RUN && DY_POOLED;
+        using XM = FlatU8Map<CIN, (PRE_X ? W : 4), C::ROWS, kWgradWaves * 64>;
+        using DM = PooledMap<COUT, (PRE_D ? H : 2), (PRE_D ? W : 4), (PRE_D ? TR : 2), kWgradWaves>;
+        uint32_t xraw[PRE_X ? XM::Q : 1];
+        PooledRaw draw[PRE_D ? DM::Q : 1];
+        auto prefetch = [&](int item) {
+            const int img = item / C::NBANDS, y0 = (item % C::NBANDS) * TR;
+            if constexpr (PRE_X) band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, img, y0, tid, xraw);
+            if constexpr (PRE_D) dy_pooled_load<COUT, H, W, TR, kWgradWaves>(dy, batch.argmax, img, y0, tid, draw);
+        };
+        if ((PRE_X || PRE_D) && (int)blockIdx.x < n_items) prefetch(blockIdx.x);
         for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+            PPO_STAMP(t_top)
             __syncthreads();
-            stage(item, s_x, s_d);
-            __syncthreads();
+            PPO_STAMP(t_bar)
+            if constexpr (PRE_X || PRE_D) {
+                const int img = item / C::NBANDS, y0 = (item % C::NBANDS) * TR;
+                if constexpr (PRE_X) band_u8x4_store<CIN, W, C::ROWS, C::XPLANE, C::G, kWgradWaves * 64>(xraw, s_x, tid);
+                else stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, kWgradWaves>(static_cast<const float *>(in_), img, y0, s_x, tid);
+                if constexpr (PRE_D) dy_pooled_store<COUT, H, W, TR, C::PWD, C::DPLANE, kWgradWaves>(draw, y0, s_d, tid);
+                else stage_band_chunk_dma<COUT, H, W, TR, C::DPLANE, 0, kWgradWaves>(dy, img, y0 + 1, s_d, tid);
+                __syncthreads();
+                if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
+            } else {
+                stage(item, s_x, s_d);
+                __syncthreads();
+            }
+            PPO_STAMP(t_staged)
             wgrad_k_loops<C, RELU>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum);
+            PPO_STAMP(t_end)
+            PPO_STAMP_ADD(0, t_bar, t_top)      // barrier wait
+            PPO_STAMP_ADD(1, t_staged, t_bar)   // staging (single-buffered: exposed)
+            PPO_STAMP_ADD(2, t_end, t_staged)   // K loop
+            PPO_STAMP_ADD(4, t_end, t_top)      // whole item
+            if (lane == 0) { PPO_STAMP_ADD(5, 1ull, 0ull) }
         }
     }
 

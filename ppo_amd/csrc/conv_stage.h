@@ -132,39 +132,78 @@ __device__ __forceinline__ void stage_band_dma(const float *__restrict__ src, in
 // written in stage_band_dma's HALO = 0 layout, s_dst[c * PLANE + r * PW + x].  One thread per 2x2 block of the band
 // (4 (argmax, g) pairs -> 4 values).  The pre-pool gradient map (the largest tensor of the backward pass: 115 MB at
 // 84x84x16x256) is then never written or read.
-template <int C, int H, int W, int TR, int PW, int PLANE, int NWAVES>
-__device__ __forceinline__ void stage_dy_pooled(const float *__restrict__ g, const uint8_t *__restrict__ argmax, int img,
-                                                int y0, float *__restrict__ s_dst, int tid)
-{
+// Two phases, so that a caller can issue the loads of the NEXT item before its K loop and compute + write LDS after
+// it: PooledRaw carries one task's loaded (g, argmax) neighbourhood untouched.
+struct PooledRaw {
+    float2 ga, gb;
+    float ga2, gb2;
+    unsigned aa, ab;
+    int ta2, tb2;
+};
+
+template <int C, int H, int W, int TR, int NWAVES>
+struct PooledMap {
     static_assert(H % 2 == 0 && W % 2 == 0 && TR % 2 == 0 && H % TR == 0, "even maps, whole bands");
-    constexpr int HO = H / 2, WO = W / 2, JB = TR / 2;
-    static_assert(WO % 2 == 0 && (HO * WO) % 2 == 0 && PLANE % 2 == 0 && PW % 2 == 0, "8-byte aligned pairs");
+    static constexpr int HO = H / 2, WO = W / 2, JB = TR / 2;
+    static_assert(WO % 2 == 0 && (HO * WO) % 2 == 0, "8-byte aligned pairs");
     // a thread takes TWO neighbouring 2x2 blocks (pooled columns k0, k0 + 1): the windows that can select their
     // elements are (j, k0 .. k0 + 2) and (j + 1, k0 .. k0 + 2) -> per row one float2 + one float of g, one ushort + one
     // byte of argmax (8 loads for 8 outputs; one block per thread needs 8 loads for 4)
-    constexpr int KP = WO / 2, NTASK = C * JB * KP;
-    for (int b = tid; b < NTASK; b += NWAVES * 64) {
-        const int c = b / (JB * KP), rem = b % (JB * KP);
-        const int jb = rem / KP, k0 = 2 * (rem % KP);
-        const int j = y0 / 2 + jb;
-        const size_t t = ((size_t)(img * C + c) * HO + j) * WO + k0;
-        const bool right = k0 + 2 < WO, down = j + 1 < HO;
-        const float2 ga = *reinterpret_cast<const float2 *>(g + t);
-        const unsigned aa = *reinterpret_cast<const unsigned short *>(argmax + t);
-        const float ga2 = right ? g[t + 2] : 0.f;
-        const int ta2 = right ? argmax[t + 2] : -1;
-        float2 gb = make_float2(0.f, 0.f);
-        unsigned ab = 0xffffu;
-        float gb2 = 0.f;
-        int tb2 = -1;
-        if (down) {
-            gb = *reinterpret_cast<const float2 *>(g + t + WO);
-            ab = *reinterpret_cast<const unsigned short *>(argmax + t + WO);
+    static constexpr int KP = WO / 2, NTASK = C * JB * KP;
+    static constexpr int Q = (NTASK + NWAVES * 64 - 1) / (NWAVES * 64);  // tasks per thread
+};
+
+template <int C, int H, int W, int TR, int NWAVES>
+__device__ __forceinline__ void dy_pooled_load(const float *__restrict__ g, const uint8_t *__restrict__ argmax, int img,
+                                               int y0, int tid, PooledRaw (&raw)[PooledMap<C, H, W, TR, NWAVES>::Q])
+{
+    using M = PooledMap<C, H, W, TR, NWAVES>;
+#pragma unroll
+    for (int q = 0; q < M::Q; ++q) {
+        const int b = tid + q * NWAVES * 64;
+        PooledRaw r{make_float2(0.f, 0.f), make_float2(0.f, 0.f), 0.f, 0.f, 0xffffu, 0xffffu, -1, -1};
+        if (b < M::NTASK) {
+            const int c = b / (M::JB * M::KP), rem = b % (M::JB * M::KP);
+            const int jb = rem / M::KP, k0 = 2 * (rem % M::KP);
+            const int j = y0 / 2 + jb;
+            const size_t t = ((size_t)(img * C + c) * M::HO + j) * M::WO + k0;
+            const bool right = k0 + 2 < M::WO, down = j + 1 < M::HO;
+            r.ga = *reinterpret_cast<const float2 *>(g + t);
+            r.aa = *reinterpret_cast<const unsigned short *>(argmax + t);
             if (right) {
-                gb2 = g[t + WO + 2];
-                tb2 = argmax[t + WO + 2];
+                r.ga2 = g[t + 2];
+                r.ta2 = argmax[t + 2];
+            }
+            if (down) {
+                r.gb = *reinterpret_cast<const float2 *>(g + t + M::WO);
+                r.ab = *reinterpret_cast<const unsigned short *>(argmax + t + M::WO);
+                if (right) {
+                    r.gb2 = g[t + M::WO + 2];
+                    r.tb2 = argmax[t + M::WO + 2];
+                }
             }
         }
+        raw[q] = r;
+    }
+}
+
+template <int C, int H, int W, int TR, int PW, int PLANE, int NWAVES>
+__device__ __forceinline__ void dy_pooled_store(const PooledRaw (&raw)[PooledMap<C, H, W, TR, NWAVES>::Q], int y0,
+                                                float *__restrict__ s_dst, int tid)
+{
+    using M = PooledMap<C, H, W, TR, NWAVES>;
+    static_assert(PLANE % 2 == 0 && PW % 2 == 0, "8-byte aligned pairs");
+#pragma unroll
+    for (int q = 0; q < M::Q; ++q) {
+        const int b = tid + q * NWAVES * 64;
+        if (b >= M::NTASK) continue;
+        const int c = b / (M::JB * M::KP), rem = b % (M::JB * M::KP);
+        const int jb = rem / M::KP, k0 = 2 * (rem % M::KP);
+        const bool down = y0 / 2 + jb + 1 < M::HO;
+        const float2 ga = raw[q].ga, gb = raw[q].gb;
+        const float ga2 = raw[q].ga2, gb2 = raw[q].gb2;
+        const unsigned aa = raw[q].aa, ab = raw[q].ab;
+        const int ta2 = raw[q].ta2, tb2 = raw[q].tb2;
         const int ta0 = aa & 0xff, ta1 = aa >> 8;
         const int tb0 = down ? (int)(ab & 0xff) : -1, tb1 = down ? (int)(ab >> 8) : -1;
         // block k0: windows (j,k0) (j,k0+1) (j+1,k0) (j+1,k0+1); block k0+1: (j,k0+1) (j,k0+2) (j+1,k0+1) (j+1,k0+2);
@@ -194,6 +233,15 @@ __device__ __forceinline__ void stage_dy_pooled(const float *__restrict__ g, con
         *reinterpret_cast<float2 *>(d + PW) = bot0;
         *reinterpret_cast<float2 *>(d + PW + 2) = bot1;
     }
+}
+
+template <int C, int H, int W, int TR, int PW, int PLANE, int NWAVES>
+__device__ __forceinline__ void stage_dy_pooled(const float *__restrict__ g, const uint8_t *__restrict__ argmax, int img,
+                                                int y0, float *__restrict__ s_dst, int tid)
+{
+    PooledRaw raw[PooledMap<C, H, W, TR, NWAVES>::Q];
+    dy_pooled_load<C, H, W, TR, NWAVES>(g, argmax, img, y0, tid, raw);
+    dy_pooled_store<C, H, W, TR, PW, PLANE, NWAVES>(raw, y0, s_dst, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------

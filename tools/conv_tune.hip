@@ -62,7 +62,8 @@ int main(int argc, char **argv)
     printf("%-34s %10s %10s\n", "kernel (batch 256)", "us", "TFLOP/s");
     for (const Geo &g : geos) {
         const double flops = 2.0 * 9 * g.cin * g.cout * g.hw * g.hw * B;
-        for (int which = 0; which < 4; ++which) {
+        for (int which = 0; which < 5; ++which) {
+            if (which == 4 && g.hw != 84) continue;  // weight gradient with the max-pool backward inside (first stack)
             if (which == 1 && g.cin <= 5) continue;  // no backward-data for the observation conv
             if (which == 3 && !(g.hw == 84 || (g.hw == 42 && g.cout == 32) )) continue;  // conv + max-pool: stack-first layers
             auto go = [&]() {
@@ -71,7 +72,11 @@ int main(int argc, char **argv)
                     rc = ppo_conv3x3_forward_f32(in, g.in_mode, w, bias, nullptr, out, B, g.cin, g.cout, g.hw, g.hw, nullptr);
                 else if (which == 1)
                     rc = ppo_conv3x3_backward_data_f32(out, w, in, nullptr, in, B, g.cin, g.cout, g.hw, g.hw, nullptr);
-                else if (which == 3)
+                else if (which == 4) {
+                    int n_slabs = 0;
+                    rc = ppo_conv3x3_backward_weight_slabs_pooled_f32(in, g.in_mode, out, (const uint8_t *)dw_big, ws, ws_bytes, B,
+                                                                      g.cin, g.cout, g.hw, g.hw, &n_slabs, nullptr);
+                } else if (which == 3)
                     rc = ppo_conv3x3_pool_forward_f32(in, g.in_mode, w, bias, out, (uint8_t *)dw_big, B, g.cin, g.cout, g.hw, g.hw,
                                                       nullptr);
                 else
@@ -92,11 +97,11 @@ int main(int argc, char **argv)
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / reps;
             char name[64];
-            snprintf(name, sizeof name, "%s %d->%d @%dx%d", which == 0 ? "fwd  " : (which == 1 ? "bwd-d" : (which == 2 ? "wgrad" : "fwd+p")),
+            snprintf(name, sizeof name, "%s %d->%d @%dx%d", which == 0 ? "fwd  " : (which == 1 ? "bwd-d" : (which == 2 ? "wgrad" : (which == 3 ? "fwd+p" : "wg+pb"))),
                      g.cin, g.cout, g.hw, g.hw);
             printf("%-34s %10.1f %10.1f\n", name, us, flops / us / 1e6);
 #ifdef PPO_TUNE_STAMPS
-            if (which <= 3) {
+            if (which <= 4) {
                 static std::vector<unsigned long long> all(8 * 8 * 1024), zeros(8 * 8 * 1024, 0);
                 CK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(ppo::ppo_tune_stamps), all.size() * 8));
                 CK(hipMemcpyToSymbol(HIP_SYMBOL(ppo::ppo_tune_stamps), zeros.data(), zeros.size() * 8));
@@ -105,7 +110,7 @@ int main(int argc, char **argv)
                 const double n = (double)st[5];
                 printf("    per item-wave cycles: barrier+stage %.0f | group prologue %.0f | K loop %.0f | compute section %.0f | item %.0f  (item-waves %.0f)\n",
                        st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, n);
-                if (which == 2)
+                if (which == 2 || which == 4)
                     printf("    wgrad per wave: prologue %.0f | fold+slab %.0f | whole kernel %.0f   (waves %d, items per wave %.1f)\n",
                            st[6] / 2048.0, st[7] / 2048.0, st[3] / 2048.0, 2048, n / 2048.0);
             }
