@@ -27,8 +27,10 @@ _ALIGN = 4  # floats: every parameter starts on a 16-byte boundary
 # bit i set: stack i runs its first convolution fused with the max-pool (bit-identical either way; the choice is
 # a measured one)
 FUSE_POOL_STACKS = int(os.environ.get("PPO_AMD_FUSE_POOL", "7"))
-# weight-gradient kernels on a second stream, overlapping the backward-data chain (0 = one stream)
-WGRAD_SIDE_STREAM = int(os.environ.get("PPO_AMD_WGRAD_STREAM", "1"))
+# weight-gradient kernels on a second stream, overlapping the backward-data chain (0 = one stream).  It paid while single
+# weight-gradient launches left the chip half empty (round 1: -4 %); with the batched, one-wave launches every kernel
+# fills the chip on its own and the second stream costs ~1 % (83.1 k vs 82.3 k env-steps/s), so the default is one stream.
+WGRAD_SIDE_STREAM = int(os.environ.get("PPO_AMD_WGRAD_STREAM", "0"))
 # the slab reductions of all convolution layers in one launch at the end of the backward pass (0 = one per layer)
 WGRAD_BATCH_REDUCE = int(os.environ.get("PPO_AMD_WGRAD_BATCH_REDUCE", "1"))
 # The four block convolutions of a stack share a geometry: their weight gradients go out as ONE launch (4 x the
