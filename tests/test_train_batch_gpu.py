@@ -62,8 +62,10 @@ def test_train_batch_micro_batches_accumulate_to_the_same_update():
     assert ctx["mini_batches"] == 2 and len(ctx["outputs"]) == 8 and split.net._adam_step == 2
     assert [c["micro_batch"] for c in seen] == [0, 1, 2, 3, 0, 1, 2, 3] and seen[0]["is_first"] and seen[-1]["is_last"]
     torch.cuda.synchronize()
-    # Adam amplifies rounding differences where |g| ~ eps; the parameters still agree far inside one learning-rate step
-    assert float((split.net.flat - ref.net.flat).abs().max()) < 0.05 * 2.5e-4
+    # Adam's first steps move a weight by ~lr * g / (|g| + eps): where |g| ~ eps = 1e-5 a rounding difference of the
+    # gradient is amplified to a fraction of a learning-rate step; everywhere else the updates coincide
+    d = (split.net.flat - ref.net.flat).abs()
+    assert float(d.max()) < 0.25 * 2 * 2.5e-4 and float(d.median()) < 1e-3 * 2.5e-4
     assert rel(split.net.exp_avg, ref.net.exp_avg) < 1e-4, "accumulated gradient differs from the one-pass gradient"
 
     # a hook that stops the epoch: no optimiser step for that minibatch
