@@ -608,7 +608,11 @@ int dispatch_conv(int cin, int cout, int h, int w_, const void *in, const float 
     PPO_CONV_CASE(UP, 16, 32, 32, 32, 8, 2, 8)      // 256 px = 16 tiles
     PPO_CONV_CASE(DOWN, 32, 16, 42, 42, 6, 2, 8)
     PPO_CONV_CASE(DOWN, 32, 16, 32, 32, 8, 2, 8)
-    PPO_CONV_CASE(SAME, 16, 16, 42, 42, 6, 2, 8)
+#ifndef PPO_TUNE_C16_MT
+#define PPO_TUNE_C16_MT 2
+#define PPO_TUNE_C16_NW 8
+#endif
+    PPO_CONV_CASE(SAME, 16, 16, 42, 42, 6, PPO_TUNE_C16_MT, PPO_TUNE_C16_NW)
     PPO_CONV_CASE(SAME, 16, 16, 32, 32, 8, 2, 8)
     PPO_CONV_CASE(SAME, 32, 32, 21, 21, 6, 2, PPO_NW32)    // 126 px = 8 tiles -> 4 groups of 2: 1 per wave
     PPO_CONV_CASE(SAME, 32, 32, 16, 16, 8, 2, PPO_NW32)    // 128 px = 8 tiles

@@ -33,6 +33,8 @@
 namespace ppo {
 namespace {
 
+constexpr int kScrPitchS = 20;  // floats per row of the transposed-epilogue scratch (see conv3x3.hip kScrPitch)
+
 struct StackTailArgs {
     const float *in;       // [n, C, H, W] block input p
     const float *w[4];     // packed weights: block0.conv0, block0.conv1, block1.conv0, block1.conv1
@@ -240,6 +242,233 @@ int launch_stack_tail(const StackTailArgs &args, hipStream_t st)
     if (grid > args.n_images) grid = args.n_images;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S::WAVES * 64), S::LDS_BYTES, st, args);
     return check_launch("stack_tail_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same four convolutions for the 16-channel stack, whose map (16 x 42 x 42 floats = 113 KB) leaves no room for a
+// second one: every layer runs IN PLACE with the map moving up one row per layer.
+//
+// A 3x3 convolution computed in bands of TR rows, top to bottom, no longer needs input row y - 1 once output row y is
+// known, so output row y can take the storage of input row y - 1.  Per band: K loop over input rows y0 - 1 .. y0 + TR
+// (accumulators in registers) -> ONE workgroup barrier (every wave has read the rows about to be overwritten) -> the
+// band's outputs are written over input rows y0 - 1 .. y0 + TR - 2.  The next band reads rows >= y0 + TR - 1: untouched,
+// so it starts without another barrier.  A plane holds H + 6 rows: layer l reads its input at row offset 5 - l and
+// leaves its output at 4 - l (four layers, four rows of head-room); the row just below each new map is cleared at the
+// layer boundary (it still holds the last row of the previous map).  The skip connection of the odd layers (the block
+// input: p or q0; backward: g or g1) is re-read from HBM — the kernel's own input or what layer 1 wrote two layers
+// earlier — as 16-byte loads in the transposed epilogue of conv3x3.hip's WIDE path, which this kernel shares, as it
+// does the K loop and the arithmetic order: results are bit-identical to the four launches.
+//
+// What it removes from the four launches: three kernel boundaries with their weight prologues and ragged tails, and
+// the HBM -> LDS band staging (with its halo re-reads and the DMA waits at every item barrier) of layers 2-4.
+template <int C, int H, int W, int TR>
+struct ShiftCfg {
+    static_assert(C == 16, "one channel tile per wave");
+    static constexpr int NW = 8;                 // waves = pixel-tile groups of a band
+    static constexpr int G = 4;
+    static constexpr int ROWS = H + 6;           // 4 rows of head-room + a halo row above and below
+    static constexpr int PLANE_RAW = ROWS * W + 2 * G;
+    static constexpr int PLANE = PLANE_RAW + ((16 - PLANE_RAW % 32) + 32) % 32;  // = 16 (mod 32)
+    static constexpr int KS = 9 * (C / 4);
+    static constexpr int NBANDS = (H + TR - 1) / TR;
+    static constexpr int NPIX = TR * W;          // pixels of a band
+    static constexpr int MTILES = (NPIX + 15) / 16;       // the last tile of a band may be partial (whole quads)
+    static constexpr int MT = MTILES / NW;                // pixel tiles per wave
+    static constexpr int LDS_MAP = C * PLANE;
+    static constexpr int SCR = MT * 16 * kScrPitchS;      // per-wave transpose scratch (floats)
+    static constexpr size_t LDS_BYTES = (size_t)(LDS_MAP + NW * SCR) * 4;
+    static_assert(H % TR == 0 && MTILES == MT * NW, "whole bands, tiles split evenly over the waves");
+    static_assert((H * W) % 4 == 0 && NPIX % 4 == 0 && W % 2 == 0, "float4 epilogue on whole quads");
+    static_assert(LDS_BYTES <= 160 * 1024, "map + scratch must fit the CU's LDS");
+};
+
+template <int C, int H, int W, int TR, bool BACKWARD>
+__global__ __launch_bounds__(512) void stack_shift_kernel(StackTailArgs a)
+{
+    using S = ShiftCfg<C, H, W, TR>;
+    constexpr int KS = S::KS, PLANE = S::PLANE, G = S::G, MT = S::MT, NW = S::NW;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int ch = lane >> 2, quad = lane & 3;  // transposed epilogue: channel ch, pixels quad*4 .. +3 of a tile
+    float *scr = smem + S::LDS_MAP + wave * S::SCR;
+
+    // per-lane constants of this wave's pixel tiles inside a band (identical for every band, layer and image)
+    int pix[MT], lofs[MT], p4[MT];
+    float hi_l[MT], hi_r[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = (wave * MT + m) * 16 + l15;
+        pix[m] = p;
+        lofs[m] = G + p - 1 + g * PLANE;  // window origin (row above, x - 1) relative to the band's first input row
+        hi_l[m] = (p % W == 0) ? 0.f : INFINITY;
+        hi_r[m] = (p % W == W - 1) ? 0.f : INFINITY;
+        p4[m] = (wave * MT + m) * 16 + quad * 4;
+    }
+
+    for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
+        const size_t img_off = (size_t)img * C * H * W;
+        __syncthreads();  // the previous image's last readers are done
+        // head-room + top halo rows (0 .. 4) and the bottom halo row (H + 5) are zero; rows 5 .. H + 4 take the image
+        for (int i = tid; i < C * 6 * W; i += NW * 64) {
+            const int c = i / (6 * W), r = (i / W) % 6, x = i % W;
+            smem[c * PLANE + G + (r < 5 ? r : H + 5) * W + x] = 0.f;
+        }
+        for (int i = tid; i < C * 2 * G; i += NW * 64)  // guards in front of and behind the rows
+            smem[(i / (2 * G)) * PLANE + ((i % (2 * G)) < G ? (i % G) : G + S::ROWS * W + (i % G))] = 0.f;
+        {   // X <- in: a channel's H * W floats are one run (flat layout), 16-byte LDS-DMA requests
+            using gptr_t = const __attribute__((address_space(1))) void *;
+            using lptr_t = __attribute__((address_space(3))) void *;
+            constexpr int N4 = H * W / 4, REQ = (N4 + 63) / 64;
+            const int w0 = __builtin_amdgcn_readfirstlane(wave);
+            for (int c = w0; c < C; c += NW) {
+                const float *g0 = a.in + img_off + (size_t)c * H * W;
+                float *l0 = smem + c * PLANE + G + 5 * W;
+#pragma unroll
+                for (int q = 0; q < REQ; ++q)
+                    if (q * 64 + lane < N4)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(g0 + (q * 64 + lane) * 4), (lptr_t)(l0 + q * 256), 16, 0, 0);
+            }
+        }
+
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            float wa[KS];
+            const float4 *pw = reinterpret_cast<const float4 *>(a.w[layer]);
+#pragma unroll
+            for (int s4 = 0; s4 < KS / 4; ++s4) {
+                const float4 v = pw[s4 * 64 + lane];
+                wa[4 * s4 + 0] = v.x, wa[4 * s4 + 1] = v.y, wa[4 * s4 + 2] = v.z, wa[4 * s4 + 3] = v.w;
+            }
+            const float bias_c = BACKWARD ? 0.f : a.bias[layer][ch];
+            const int odd = layer & 1;
+            // skip connection of the odd layers: the block input = the kernel's input (layer 1) or layer 1's output (layer 3)
+            const float *res = odd ? (layer == 1 ? a.in : a.save[1]) + img_off : nullptr;
+            const float *mask = BACKWARD ? a.mask[layer] + img_off : nullptr;
+            float *save = a.save[layer] ? a.save[layer] + img_off : nullptr;
+            const int in_row = 5 - layer;  // plane row of this layer's input row y = 0
+
+            __syncthreads();  // the source map is complete (DMA landed / previous layer's LDS writes and row clear)
+#pragma unroll 1
+            for (int band = 0; band < S::NBANDS; ++band) {
+                const int y0 = band * TR;
+                const int chan_off = ch * (H * W) + y0 * W;
+                // gate / skip operands of this band: requested now, consumed after the K loop
+                float4 gate4[MT], res4[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bool live = p4[m] < S::NPIX;  // a quad is whole or absent (NPIX % 4 == 0)
+                    gate4[m] = (mask && live) ? *reinterpret_cast<const float4 *>(mask + chan_off + p4[m]) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    res4[m] = (res && live) ? *reinterpret_cast<const float4 *>(res + chan_off + p4[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                int base[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) base[m] = lofs[m] + (y0 - 1 + in_row) * W;
+                f32x4 acc[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+                // K loop: the block pipeline of conv3x3.hip / stack_tail_kernel
+                constexpr int SB = 4;
+                constexpr int NB = (KS + SB - 1) / SB;
+                float raw[2][SB][MT];
+                auto load_block = [&](int j, float (&r)[SB][MT]) {
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int s = j * SB + u;
+                        if (s < KS) {
+                            const int tap = s / (C / 4), cs = s % (C / 4);
+                            const int tap_off = (tap / 3) * W + (tap % 3);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) r[u][m] = smem[base[m] + cs * 4 * PLANE + tap_off];
+                        }
+                    }
+                };
+                load_block(0, raw[0]);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    float bv[SB][MT];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int s = j * SB + u;
+                        if (s < KS) {
+                            const int kx = (s / (C / 4)) % 3;
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                float x = raw[j & 1][u][m];
+                                if (kx != 1) {
+                                    const float hi = kx == 0 ? hi_l[m] : hi_r[m];
+                                    x = __builtin_amdgcn_fmed3f(x, BACKWARD ? -hi : 0.f, hi);
+                                } else if (!BACKWARD) {
+                                    x = relu1(x);
+                                }
+                                bv[u][m] = x;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 1 < NB) load_block(j + 1, raw[(j + 1) & 1]);
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int s = j * SB + u;
+                        if (s < KS) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) acc[m] = mfma16(wa[s], bv[u][m], acc[m]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+
+                // MFMA layout -> [channel][16 pixels] rows of the wave's scratch (DS operations of a wave are in order)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) scr[(m * 16 + g * 4 + r) * kScrPitchS + l15] = acc[m][r];
+                __syncthreads();  // every wave has read the input rows this band's outputs overwrite
+                float *out_row = smem + ch * PLANE + G + (y0 + in_row - 1) * W;  // output row y sits where input row y - 1 sat
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if (p4[m] >= S::NPIX) continue;
+                    const float4 o = *reinterpret_cast<const float4 *>(scr + (m * 16 + ch) * kScrPitchS + quad * 4);
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+                    const float gv[4] = {gate4[m].x, gate4[m].y, gate4[m].z, gate4[m].w};
+                    const float rv[4] = {res4[m].x, res4[m].y, res4[m].z, res4[m].w};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float val = ov[e] + bias_c;
+                        if constexpr (BACKWARD) val = gv[e] > 0.f ? val : 0.f;
+                        v[e] = val + rv[e];
+                    }
+                    if (layer < 3) {  // the next layer's input (8-byte stores: rows are W = 2 (mod 4) floats apart)
+                        *reinterpret_cast<float2 *>(out_row + p4[m]) = make_float2(v[0], v[1]);
+                        *reinterpret_cast<float2 *>(out_row + p4[m] + 2) = make_float2(v[2], v[3]);
+                    }
+                    if (save) *reinterpret_cast<float4 *>(save + chan_off + p4[m]) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            // the row below the new map still holds the old map's last row: it is the next layer's bottom halo
+            if (layer < 3)
+                for (int i = tid; i < C * W; i += NW * 64) smem[(i / W) * PLANE + G + (H + in_row - 1) * W + i % W] = 0.f;
+        }
+    }
+}
+
+template <int C, int H, int W, int TR, bool BACKWARD>
+int launch_stack_shift(const StackTailArgs &args, hipStream_t st)
+{
+    using S = ShiftCfg<C, H, W, TR>;
+    auto kern = stack_shift_kernel<C, H, W, TR, BACKWARD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)S::LDS_BYTES);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_shift: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    int grid = 256;  // one workgroup per CU (150 KB of LDS each)
+    if (grid > args.n_images) grid = args.n_images;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S::LDS_BYTES, st, args);
+    return check_launch("stack_shift_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -637,6 +866,7 @@ int launch_stack_full(const StackFullArgs &args, hipStream_t st)
 extern "C" int ppo_impala_stack_tail_supported(int channels, int h, int w)
 {
     // 84x84 observations: 21x21 and 11x11; 64x64 (procgen): 16x16 and 8x8
+    if (channels == 16) return (h == 42 && w == 42) || (h == 32 && w == 32);  // in-place shifted form (stack_shift_kernel)
     return channels == 32 && ((h == 11 && w == 11) || (h == 21 && w == 21) || (h == 16 && w == 16) || (h == 8 && w == 8));
 }
 
@@ -667,6 +897,14 @@ extern "C" int ppo_impala_stack_tail_forward_f32(const float *in, const float *c
     args.save[3] = q1;
     args.n_images = n_images;
     hipStream_t st = as_stream(stream);
+    if (channels == 16) {
+        // the skip connection of the second block is re-read from q0, so q0 is required even when nothing else is kept
+        if (!q0) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_f32: the 16-channel form needs q0 (its second block re-reads it)");
+        if (!aligned(in, 16) || !aligned(q0, 16) || !aligned(q1, 16) || (a0 && !aligned(a0, 16)) || (a1 && !aligned(a1, 16)))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_forward_f32: the 16-channel form needs 16-byte aligned maps");
+        if (h == 42 && w == 42) return launch_stack_shift<16, 42, 42, 6, false>(args, st);
+        if (h == 32 && w == 32) return launch_stack_shift<16, 32, 32, 8, false>(args, st);
+    }
     if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, false>(args, st);
     if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, false>(args, st);
     if (channels == 32 && h == 16 && w == 16) return launch_stack_tail<32, 16, 16, 4, 4, PPO_TAIL_SPLIT, false>(args, st);
@@ -700,6 +938,14 @@ extern "C" int ppo_impala_stack_tail_backward_f32(const float *g, const float *c
     args.save[3] = g0;
     args.n_images = n_images;
     hipStream_t st = as_stream(stream);
+    if (channels == 16) {
+        for (const void *ptr : {(const void *)g, (const void *)da1, (const void *)g1, (const void *)da0, (const void *)g0,
+                                (const void *)masks[0], (const void *)masks[1], (const void *)masks[2], (const void *)masks[3]})
+            if (!aligned(ptr, 16))
+                return fail(PPO_E_ALIGN, "ppo_impala_stack_tail_backward_f32: the 16-channel form needs 16-byte aligned maps");
+        if (h == 42 && w == 42) return launch_stack_shift<16, 42, 42, 6, true>(args, st);
+        if (h == 32 && w == 32) return launch_stack_shift<16, 32, 32, 8, true>(args, st);
+    }
     if (channels == 32 && h == 11 && w == 11) return launch_stack_tail<32, 11, 11, 2, 4, PPO_TAIL_SPLIT, true>(args, st);
     if (channels == 32 && h == 21 && w == 21) return launch_stack_tail<32, 21, 21, 7, 4, PPO_TAIL_SPLIT, true>(args, st);
     if (channels == 32 && h == 16 && w == 16) return launch_stack_tail<32, 16, 16, 4, 4, PPO_TAIL_SPLIT, true>(args, st);

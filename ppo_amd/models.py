@@ -60,6 +60,13 @@ FUSE_STACK_FULL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL_BWD", "0"))
 # ... and the same for their backward-data chain, as a bit mask over the stacks (per 256-sample step, same box:
 # 1.476 ms with mask 0, 1.450 with 4 (11x11), 1.404 with 2 (21x21), 1.408 with 6).
 FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "6"))
+# The 16-channel stack's blocks (42x42 / 32x32: the map fills most of a CU's LDS) as the in-place, row-shifted form of the
+# same kernel family (csrc/stack_fused.hip stack_shift_kernel); 0 = four convolution launches.  One workgroup per image
+# and per CU: measured at batch 256 forward 0.406 -> 0.395 ms, backward-data (bit 0 of the mask above) +10 us, so the
+# forward uses it and the backward does not; at 128 images (a rollout group) it leaves half the chip idle (0.296 ->
+# 0.325 ms), so batches below FUSE_STACK16_MIN_BATCH keep the four launches.  Same bits either way.
+FUSE_STACK16 = int(os.environ.get("PPO_AMD_FUSE_STACK16", "1"))
+FUSE_STACK16_MIN_BATCH = int(os.environ.get("PPO_AMD_FUSE_STACK16_MIN_BATCH", "192"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -568,11 +575,12 @@ class DualHeadNet:
             self._tail_ptrs[("full", si)] = cached
         return cached
 
-    def _stack_tail_ptrs(self, si, cout, ho, wo):
+    def _stack_tail_ptrs(self, si, cout, ho, wo, batch=1 << 30):
         """Host arrays of the four packed-weight / bias pointers of stack si's residual blocks for the fused
         kernel, or None when it does not apply.  The arrays are cached: packed buffers and parameter views keep
         their addresses for the life of the net."""
-        if not FUSE_STACK_TAIL or self.spec.n_block != 2 or not self.lib.ppo_impala_stack_tail_supported(cout, ho, wo):
+        if not FUSE_STACK_TAIL or self.spec.n_block != 2 or not self.lib.ppo_impala_stack_tail_supported(cout, ho, wo) \
+                or (cout == 16 and (not FUSE_STACK16 or batch < FUSE_STACK16_MIN_BATCH)):
             return None
         cached = self._tail_ptrs.get(si)
         if cached is None:
@@ -626,7 +634,7 @@ class DualHeadNet:
                 self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
             acts[f"in{si}"], acts[f"idx{si}"] = cur, idx
             q = p
-            tail = self._stack_tail_ptrs(si, cout, ho, wo)
+            tail = self._stack_tail_ptrs(si, cout, ho, wo, B)
             if tail is not None:
                 names = [f"{tag}a{si}_0", f"{tag}q{si}_0", f"{tag}a{si}_1", f"{tag}q{si}_1"]
                 a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
@@ -639,8 +647,9 @@ class DualHeadNet:
                     cur, cur_mode = q1, IN_NONE
                     continue
                 # inference needs only the stack's output; training keeps the maps the backward pass reads
+                # (the 16-channel form re-reads q0 for its second block's skip connection: it is written in inference too)
                 self._call("ppo_impala_stack_tail_forward_f32", _p(p), tail[0], tail[1], _p(a0) if train else None,
-                           _p(q0) if train else None, _p(a1) if train else None, _p(q1), B, cout, ho, wo)
+                           _p(q0) if (train or cout == 16) else None, _p(a1) if train else None, _p(q1), B, cout, ho, wo)
                 acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"] = p, a0, q0, a1
                 cur, cur_mode = q1, IN_NONE
                 continue
@@ -948,7 +957,7 @@ class DualHeadNet:
         """Host array of the four backward-data packed weights of stack si's blocks in processing order
         (block1.conv1, block1.conv0, block0.conv1, block0.conv0), or None when the fused kernel does not apply."""
         if not (FUSE_STACK_TAIL and FUSE_STACK_TAIL_BWD >> si & 1) or self.spec.n_block != 2 \
-                or not self.lib.ppo_impala_stack_tail_supported(cout, ho, wo):
+                or not self.lib.ppo_impala_stack_tail_supported(cout, ho, wo) or (cout == 16 and not FUSE_STACK16):
             return None
         cached = self._tail_ptrs.get(("bwd", si))
         if cached is None:

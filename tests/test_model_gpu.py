@@ -300,10 +300,12 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
     monkeypatch.setattr(models, "FUSE_STACK_FULL", 1)
     monkeypatch.setattr(models, "FUSE_STACK_FULL_BWD", 1)
     monkeypatch.setattr(models, "FUSE_STACK_CHAIN", 1)
-    monkeypatch.setattr(models, "FUSE_STACK_TAIL_BWD", 6)  # both backward instances, whatever the default mask
+    monkeypatch.setattr(models, "FUSE_STACK_TAIL_BWD", 7)  # every backward instance, whatever the default mask
+    monkeypatch.setattr(models, "FUSE_STACK16_MIN_BATCH", 1)  # ... and the 16-channel form at every batch size
     a = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     assert a.lib.ppo_impala_stack_tail_supported(32, 11, 11) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 21, 21) == 1
-    assert a.lib.ppo_impala_stack_tail_supported(16, 42, 42) == 0 and a.lib.ppo_impala_stack_tail_supported(32, 8, 8) == 1
+    assert a.lib.ppo_impala_stack_tail_supported(16, 42, 42) == 1 and a.lib.ppo_impala_stack_tail_supported(32, 8, 8) == 1
+    assert a.lib.ppo_impala_stack_tail_supported(16, 21, 21) == 0
     assert a.lib.ppo_impala_stack_full_supported(32, 16, 16) == 1 and a.lib.ppo_impala_stack_full_supported(32, 11, 11) == 0
     b = models.DualHeadNet("impala", dims, nA, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     b.load_state_dict(a.state_dict())
@@ -313,7 +315,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
         for _ in range(2):  # the second pass replays the recorded launch plan
             monkeypatch.setattr(models, "FUSE_STACK_TAIL", 1)
             ha = a.forward(x)["_heads"].clone()
-            assert {1, ("full", 2)} <= set(a._tail_ptrs), "the fused paths did not engage (tail of stack 1, whole stack 2)"
+            assert {0, 1, ("full", 2)} <= set(a._tail_ptrs), "the fused paths did not engage (blocks of stacks 0 and 1, whole stack 2)"
             monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
             hb = b.forward(x)["_heads"].clone()
             assert not b._tail_ptrs
@@ -326,7 +328,7 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
         monkeypatch.setattr(models, "WGRAD_POOLED_DY", 1)     # first stack's pool backward inside its weight-gradient kernel
         monkeypatch.setattr(models, "WGRAD_BATCH_LAUNCH", 1)  # one weight-gradient launch per stack's blocks ...
         acts_a = a.encode(x, train=True)
-        saved = {k: acts_a[k].clone() for k in ("q1_0_in", "a1_0", "q1_1_in", "a1_1", "in2", "idx2",
+        saved = {k: acts_a[k].clone() for k in ("q0_0_in", "a0_0", "q0_1_in", "a0_1", "in1", "q1_0_in", "a1_0", "q1_1_in", "a1_1", "in2", "idx2",
                                                 "q2_0_in", "a2_0", "q2_1_in", "a2_1", "flat")}
         a.ppo_minibatch(x, actions, pac, logp, adv, ret)
         monkeypatch.setattr(models, "FUSE_STACK_TAIL", 0)
@@ -353,4 +355,4 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
         a.ppo_minibatch(x, actions, pac, logp, adv, ret)
         torch.cuda.synchronize()
         assert torch.equal(a.grad, again), "the batched weight-gradient launch is not deterministic"
-        assert {("bwd", 1), ("full_bwd", 2)} <= set(a._tail_ptrs), "the fused backward did not engage"
+        assert {("bwd", 0), ("bwd", 1), ("full_bwd", 2)} <= set(a._tail_ptrs), "the fused backward did not engage"
