@@ -59,12 +59,13 @@ FUSE_STACK_CHAIN = int(os.environ.get("PPO_AMD_FUSE_STACK_CHAIN", "1"))
 FUSE_STACK_FULL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL_BWD", "0"))
 # ... and the same for their backward-data chain, as a bit mask over the stacks (per 256-sample step, same box:
 # 1.476 ms with mask 0, 1.450 with 4 (11x11), 1.404 with 2 (21x21), 1.408 with 6).
-FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "6"))
+FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "7"))
 # The 16-channel stack's blocks (42x42 / 32x32: the map fills most of a CU's LDS) as the in-place, row-shifted form of the
-# same kernel family (csrc/stack_fused.hip stack_shift_kernel); 0 = four convolution launches.  One workgroup per image
-# and per CU: measured at batch 256 forward 0.406 -> 0.395 ms, backward-data (bit 0 of the mask above) +10 us, so the
-# forward uses it and the backward does not; at 128 images (a rollout group) it leaves half the chip idle (0.296 ->
-# 0.325 ms), so batches below FUSE_STACK16_MIN_BATCH keep the four launches.  Same bits either way.
+# same kernel family (csrc/stack_fused.hip stack_shift_kernel); 0 = four convolution launches.  One 16-wave workgroup per
+# image and per CU, two wave groups half a band apart (one in its K loop while the other runs its epilogue): measured at
+# batch 256 forward 0.398 -> 0.393 ms, training step 1.219 -> 1.186 ms with the backward-data form too (bit 0 of the mask
+# above).  At 128 images (a rollout group) it leaves half the chip idle (0.296 -> 0.325 ms), so batches below
+# FUSE_STACK16_MIN_BATCH keep the four launches.  Same bits either way.
 FUSE_STACK16 = int(os.environ.get("PPO_AMD_FUSE_STACK16", "1"))
 FUSE_STACK16_MIN_BATCH = int(os.environ.get("PPO_AMD_FUSE_STACK16_MIN_BATCH", "192"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
