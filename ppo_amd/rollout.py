@@ -25,9 +25,10 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, parallel
+from . import _lib, parallel, value_quality
 from .config import args
 from .models import AdamState
+from .returns import calculate_bootstrapped_returns
 
 
 # 1: replay the rollout forward of each env group as a hipGraph.  Measured on MI355X / ROCm 7.2: 0.794 ms per
@@ -563,6 +564,47 @@ class Runner:
                    float(args.lambda_policy), float(args.lambda_value), _lib.PPO_SCAN_AUTO)
         if self.tvf is not None:
             self.tvf.tvf_returns[..., 0].copy_(self.tvf.calculate_tvf_returns(value_head="ext"))
+        if not args.disable_logging:
+            self.log_returns(value)
+
+    @property
+    def reward_scale(self):
+        """What the env stack multiplied the rewards by (rl/rollout.py:1793-1802)."""
+        if args.env.reward_normalization == "off":
+            return 1.0
+        if args.env.reward_normalization != "rms":
+            raise ValueError(f"Invalid reward normalization {args.env.reward_normalization}")
+        from . import wrappers
+        norm = wrappers.get_wrapper(self.vec_env, wrappers.VecNormalizeRewardWrapper)
+        return 1.0 if norm is None else float(1.0 / norm.std)
+
+    def log_returns(self, value_estimate):
+        """The diagnostics the reference writes at the end of calculate_returns (rl/rollout.py:1199, 1252-1285):
+        moments of the value estimates / advantages / returns every batch; feature statistics and explained
+        variance every 4th batch unless --disable_ev."""
+        N = self.N
+        head0 = self.value_heads[0]
+        named = [("*ext_value_estimates", value_estimate, {}), ("adv_ext", self.advantage, {"display_width": 0})]
+        for i, head in enumerate(self.value_heads):
+            named.append((f"*return_{head}", self.returns[..., i], {"display_width": 0}))
+            named.append((f"value_{head}", self.value[..., i], {"display_name": "v_" + head}))
+        value_quality.log_batch_moments(self.log, named)
+        self.log.watch_mean("reward_scale", self.reward_scale, display_width=0, history_length=1)
+        self.log.watch_mean("entropy_bonus", self.current_entropy_bonus, display_width=0, history_length=1)
+        self.log.watch("*gamma", args.gamma)
+        if self.tvf is not None:
+            self.log.watch("*tvf_gamma", args.tvf.gamma)
+            self.log.watch_stats("*tvf_return_ext", self.tvf.tvf_returns[:, :, -1].cpu().numpy())
+        if args.disable_ev or self.batch_counter % 4 != 3:
+            return
+        value_quality.log_feature_statistics(
+            self.log, self.detached_batch_forward(self.all_obs[0], output="full", include_features=True))
+        ext_value = self.value[..., self.value_heads.index("ext")] if "ext" in self.value_heads else self.value[..., 0]
+        targets = calculate_bootstrapped_returns(self.ext_rewards, self.terminals, ext_value[N], float(args.gamma))
+        if self.tvf is not None:
+            self.tvf.log_tvf_curve_quality(ext_value[:N], targets)
+        else:
+            value_quality.log_dna_value_quality(self.log, ext_value[:N], targets)
 
     # ------------------------------------------------------------------ training
     def _normalize_advantages(self):

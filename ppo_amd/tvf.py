@@ -254,6 +254,19 @@ class TVFRunnerModule:
             n_step=tvf_n_step or args.tvf_return_n_step, max_samples=args.tvf.return_samples,
             use_log_interpolation=args.tvf.return_use_log_interpolation)
 
+    def log_tvf_curve_quality(self, ext_values, ext_targets):
+        """Explained variance of the truncated-value curve against fixed n-step Monte-Carlo targets, and of the
+        ext value head against bootstrapped returns (rl/tvf.py:274-301)."""
+        from . import value_quality
+        from .config import args
+        r = self.runner
+        targets = self.calculate_tvf_returns(value_head="ext", tvf_return_distribution="fixed", tvf_n_step=args.n_steps)
+        estimates = self.tvf_value[:r.N, :, :, 0]
+        value_quality.log_curve_quality(r.log, estimates, targets, r.tvf_horizons)
+        ev = value_quality.explained_variance(value_quality._host(ext_values).ravel(),
+                                              value_quality._host(ext_targets).ravel())
+        r.log.watch_mean("*ev_ext", ev, history_length=1)
+
     def get_tvf_ext_value_estimate(self, new_gamma: float):
         """[N+1, A] value estimate for GAE: the longest horizon (rl/tvf.py:304-338), re-discounted when the
         policy gamma differs from the TVF gamma (:353-360)."""

@@ -46,6 +46,8 @@ def test_cartpole_mlp_learns_through_the_process_pool():
             lengths.append(r.N * r.A / max(done, 1))
         stats = r.fetch_stats()
         assert np.isfinite(stats["loss_policy"]) and torch.isfinite(r.net.flat).all()
+        norm = wrappers.get_wrapper(r.vec_env, wrappers.VecNormalizeRewardWrapper)
+        assert r.reward_scale == pytest.approx(1.0 / float(norm.std)) and r.reward_scale < 1.0  # rl/rollout.py:1793
         early, late = np.mean(lengths[:3]), np.mean(lengths[-3:])
         assert early < 40, lengths  # random play: ~20 steps per episode
         assert late > 2.5 * early, lengths  # PPO learned to balance
@@ -349,3 +351,94 @@ def test_atari_wrapper_stack_through_the_process_pool_and_runner():
         assert torch.isfinite(r.ext_rewards).all() and torch.isfinite(r.net.flat).all() and r.net._adam_step == 8
     finally:
         r.vec_env.close()
+
+
+def test_runner_logs_value_quality_every_fourth_batch():
+    """rl/rollout.py:1252-1285: moments of advantages / returns / values every batch; feature statistics and
+    explained variance when batch_counter % 4 == 3 (skipped under --disable_ev); the numbers are those of the
+    runner's own buffers."""
+    from ppo_amd import value_quality as vq
+    args.setup(["--agents=16", "--n_steps=8", "--model_architecture=single", "--model_encoder=impala",
+                "--env_type=synthetic", "--env_embed_time=False", "--seed=5", "--device=cuda",
+                "--policy_opt_mini_batch_size=64", "--policy_opt_epochs=1"])
+    torch.manual_seed(5)
+    np.random.seed(5)
+    shape, nA = envs.get_env_spec()
+    model = models.TVFModel("impala", input_dims=shape, actions=nA, device="cuda", architecture="single",
+                            hidden_units=256, head_scale=0.1, head_bias=True)
+    log = logger.Logger(quiet=True)
+    r = rollout.Runner(model, log)
+    r.vec_env = envs.create_envs_classic()
+    r.reset()
+    for it in range(4):
+        r.generate_rollout()
+        r.calculate_returns()
+        assert ("ev_ext" in log) == (it == 3), it
+        assert log["adv_ext_mean"] == pytest.approx(float(r.advantage.double().mean()), abs=1e-9)
+        assert log["*return_ext_std"] == pytest.approx(float(r.returns.double().std(unbiased=False)), rel=1e-9)
+        r.train()
+    N = r.N
+    values, rewards = r.value[:N, :, 0].cpu().numpy(), r.ext_rewards.cpu().numpy()
+    targets = O.calculate_bootstrapped_returns(rewards, r.terminals.cpu().numpy(), r.value[N, :, 0].cpu().numpy(), args.gamma)
+    want = vq.explained_variance(values.ravel(), targets.ravel())
+    assert log["ev_ext"] == pytest.approx(want, abs=1e-5) and log["ev_average"] == log["ev_ext"]
+    assert log["z_target_var"] == pytest.approx(float(np.var(targets.astype(np.float64))), rel=1e-4)
+    for key in ("*policy_features_sparsity", "*policy_raw_features_std", "reward_scale", "entropy_bonus", "*gamma",
+                "value_ext_mean", "*ext_value_estimates_std"):
+        assert key in log, key
+    assert 0.0 <= log["*policy_features_sparsity"] < 1.0
+    assert log["reward_scale"] == 1.0  # the device-resident synthetic env stack has no reward normaliser
+    # --disable_ev: the per-batch moments stay, the explained-variance block goes
+    args.disable_ev = True
+    log2 = logger.Logger(quiet=True)
+    r.log = log2
+    r.batch_counter = 3
+    r.generate_rollout()
+    r.calculate_returns()
+    assert "adv_ext_mean" in log2 and "ev_ext" not in log2 and "*policy_features_std" not in log2
+
+
+def test_tvf_runner_logs_curve_quality():
+    """rl/tvf.py:274-301: with TVF on, every 4th batch logs the explained variance of the truncated-value curve
+    against fixed n-step Monte-Carlo targets (ev_first / ev_mid / ev_last / ev_average) and *ev_ext."""
+    from ppo_amd import value_quality as vq
+    args.setup(["--agents=8", "--n_steps=16", "--model_architecture=dual", "--model_encoder=mlp",
+                "--model_hidden_units=64", "--env_type=mujoco", "--env_name=Fake", "--seed=9", "--device=cuda",
+                "--tvf_enabled=True", "--tvf_value_heads=8", "--tvf_max_horizon=100", "--tvf_return_samples=4",
+                "--policy_opt_mini_batch_size=64", "--value_opt_mini_batch_size=64", "--distil_opt_mini_batch_size=64",
+                "--env_reward_normalization=off"])
+    torch.manual_seed(9)
+    np.random.seed(9)
+    horizons, weights = tvf.get_value_head_horizons(args.tvf.value_heads, args.tvf.max_horizon, args.tvf.head_spacing,
+                                                    include_weight=True)
+    model = models.TVFModel("mlp", input_dims=(11,), actions=3, device="cuda", architecture="dual", hidden_units=64,
+                            encoder_activation_fn="tanh", tvf_fixed_head_horizons=horizons,
+                            tvf_fixed_head_weights=weights, head_scale=0.1, head_bias=True)
+    log = logger.Logger(quiet=True)
+    r = rollout.Runner(model, log, action_dist="gaussian")
+    r.vec_env = FloatVecEnv(8, 11, seed=4)
+    r.reset()
+    r.batch_counter = 3
+    r.generate_rollout()
+    r.calculate_returns()
+    N, K = r.N, len(horizons)
+    est = r.tvf.tvf_value[:N, :, :, 0].cpu().numpy()
+    tv = r.tvf.tvf_value[..., 0].cpu().numpy()
+    targets = OT.get_return_estimate(mode=args.tvf.return_mode, distribution="fixed", gamma=args.tvf.gamma,
+                                     rewards=r.ext_rewards.cpu().numpy(), dones=r.terminals.cpu().numpy(),
+                                     required_horizons=np.asarray(horizons), value_sample_horizons=np.asarray(horizons),
+                                     value_samples=tv, n_step=args.n_steps, max_samples=args.tvf.return_samples)
+    want = Recorder()
+    vq.log_curve_quality(want, est, targets, horizons)
+    for key in ("ev_first", "ev_mid", "ev_last", "ev_average", "nev_0", "var_1"):
+        assert log[key] == pytest.approx(want.got[key], abs=2e-4), key
+    assert "*ev_ext" in log and "ev_ext" not in log and "*tvf_return_ext_mean" in log and "*tvf_gamma" in log
+    assert "*value_features_sparsity" in log
+
+
+class Recorder:
+    def __init__(self):
+        self.got = {}
+
+    def watch_mean(self, key, value, **kw):
+        self.got[key] = float(value)
