@@ -15,20 +15,19 @@ def merge_moments(mean, var, count, batch_mean, batch_var, batch_count):
 
 
 class RunningMeanStd:
+    """mean / var are float64 arrays of `shape`; count starts at epsilon so the first batch dominates."""
+
     def __init__(self, epsilon=1e-4, shape=()):
-        self.mean = np.zeros(shape, "float64")
-        self.var = np.ones(shape, "float64")
-        self.count = epsilon
+        self.restore_state((np.zeros(shape, "float64"), np.ones(shape, "float64"), epsilon))
 
     def update(self, x):
-        if type(x) in (float, int):
+        if type(x) in (float, int):  # a scalar is a batch of one with no spread
             self.update_from_moments(x, 0, 1)
         else:
             self.update_from_moments(np.mean(x, axis=0), np.var(x, axis=0), x.shape[0])
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
-        self.mean, self.var, self.count = merge_moments(self.mean, self.var, self.count, batch_mean, batch_var,
-                                                        batch_count)
+        self.restore_state(merge_moments(*self.save_state(), batch_mean, batch_var, batch_count))
 
     def save_state(self):
         return (self.mean, self.var, self.count)

@@ -74,27 +74,30 @@ class VecNormalizeRewardWrapper(VecWrapper):
         R <- r + gamma * R * (1 - done);  running var over every R seen;  r' = clip(r / sqrt(var + 1e-2), +-clip) * scale
 
     `moments_sync`, if given, maps np.array([sum, sum_sq, n]) of this step's R to the same moments summed
-    over all data-parallel ranks, so every rank keeps the normaliser a single process with all envs would."""
+    over all data-parallel ranks, so every rank keeps the normaliser a single process with all envs would.
+
+    Attribute names (`ret_rms`, `ret_var`, `current_returns`, `std`, `mean`) and the save_state keys are the
+    reference's (rl/wrappers.py:795-919): checkpoints and the trainer's `reward_scale` read them."""
+
+    MODES = ("rms", "ema", "custom")
+    STATE_KEYS = ("ret_rms", "ret_var", "current_returns")
+    epsilon = 1e-2  # added to the variance under the square root
 
     def __init__(self, env, initial_state=None, gamma: float = 1.0, clip: float = 10.0, scale: float = 1.0,
                  returns_transform=lambda x: x, mode: str = "rms", ed_type=None, ed_bias: float = 1.0,
                  ema_horizon: float = 5e6, moments_sync=None):
-        super().__init__(env)
         if ed_type is not None:
             raise NotImplementedError("episodic discounting normalisation is outside the PPO hot path")
-        if mode not in ("rms", "ema", "custom"):
+        if mode not in self.MODES:
             raise ValueError(f"Invalid mode {mode}")
-        self.clip = clip
-        self.epsilon = 1e-2
+        super().__init__(env)
+        # options
+        self.mode, self.gamma, self.clip, self.scale = mode, gamma, clip, scale
+        self.returns_transform, self.ema_horizon, self.moments_sync = returns_transform, ema_horizon, moments_sync
+        # state: per-env discounted return so far, running moments of all of them, EMA variance (mode "ema")
         self.current_returns = np.zeros([env.num_envs], dtype=np.float32)
         self.ret_rms = RunningMeanStd(shape=())
-        self.gamma = gamma
-        self.scale = scale
-        self.mode = mode
-        self.returns_transform = returns_transform
         self.ret_var = 0.0
-        self.ema_horizon = ema_horizon
-        self.moments_sync = moments_sync
         if initial_state is not None:
             self.ret_rms.restore_state(initial_state)
 
@@ -111,22 +114,25 @@ class VecNormalizeRewardWrapper(VecWrapper):
         mean = s / n
         self.ret_rms.update_from_moments(mean, max(ss / n - mean * mean, 0.0), n)
 
-    def step(self, actions):
-        obs, rewards, dones, infos = self.env.step(actions)
+    def _track(self, rewards, dones):
+        """Advance the per-env discounted returns by one step and fold them into the running statistics."""
         self.current_returns = rewards + self.gamma * self.current_returns * (1 - dones)
         self._update(self.returns_transform(self.current_returns))
         if self.mode == "ema":
             alpha = 1 - (len(dones) / min(self.ret_rms.count, self.ema_horizon))
             self.ret_var = alpha * self.ret_var + (1 - alpha) * np.var(self.current_returns)
-        scaled = rewards / self.std
+
+    def step(self, actions):
+        obs, rewards, dones, infos = self.env.step(actions)
+        self._track(rewards, dones)
+        out = rewards / self.std
         if self.clip is not None and self.clip >= 0:
-            clipped = np.clip(scaled, -self.clip, +self.clip)
-            clips = np.sum(clipped != scaled)
-            if clips > 0:
-                infos[0]["reward_clips"] = clips
-            scaled = clipped
-        scaled = scaled * self.scale
-        return obs, scaled, dones, infos
+            bounded = np.clip(out, -self.clip, +self.clip)
+            n_clipped = np.sum(bounded != out)
+            if n_clipped > 0:
+                infos[0]["reward_clips"] = n_clipped
+            out = bounded
+        return obs, out * self.scale, dones, infos
 
     @property
     def mean(self):
@@ -137,11 +143,8 @@ class VecNormalizeRewardWrapper(VecWrapper):
         return math.sqrt((self.ret_rms.var if self.mode == "rms" else self.ret_var) + self.epsilon)
 
     def save_state(self, buffer):
-        buffer["ret_rms"] = self.ret_rms.save_state()
-        buffer["ret_var"] = self.ret_var
-        buffer["current_returns"] = self.current_returns
+        buffer.update(ret_rms=self.ret_rms.save_state(), ret_var=self.ret_var, current_returns=self.current_returns)
 
     def restore_state(self, buffer):
-        self.ret_var = buffer["ret_var"]
-        self.ret_rms.restore_state(buffer["ret_rms"])
-        self.current_returns = buffer["current_returns"]
+        moments, self.ret_var, self.current_returns = (buffer[k] for k in self.STATE_KEYS)
+        self.ret_rms.restore_state(moments)
