@@ -15,6 +15,8 @@
 // Operands that are not 16-byte friendly (heads: 13 rows) take a scalar path.  Small grids are
 // filled with split-K: slices write [S][M][N] partials and gemm_finalize sums them in slice order
 // (deterministic) and applies the epilogue.
+#include <algorithm>
+
 #include "common.h"
 #include "mfma.h"
 
@@ -45,6 +47,7 @@ struct GemmArgs {
     int k_per_slice;
     int split;
     int vec_a, vec_b;    // operand may be fetched with aligned float4 loads along its contiguous axis
+    int vec_c;           // C (and bias, mask) can move as aligned float4 along n
 };
 
 // One operand slab (64 tile rows x 32 k) -> registers -> LDS.  `tfast`: the tile axis (m or n) is the
@@ -54,8 +57,23 @@ struct Slab {
     float4 v[kSlabF4];
 };
 
-__device__ __forceinline__ void slab_load(Slab &s, const float *__restrict__ P, int64_t st, int64_t sk, bool kfast,
-                                          bool vec, int t0, int rows, int k0, int kend, int tid)
+// Operands are read through buffer descriptors: an element outside the matrix gets the offset kOutside, which the
+// hardware range check turns into zeros.  (A predicated global load - `in ? P[i] : 0`, however it is spelled - is
+// compiled to a branch around the load, and the wait-count bookkeeping at every such join falls back to vmcnt(0):
+// the whole prefetch serialised, 1.5 us per slab.)  Offsets are 32-bit byte offsets: the host checks the operands
+// are below kBufferBytes.
+constexpr uint32_t kBufferBytes = 0x80000000u;
+constexpr int kOutside = -16;  // 0xfffffff0 as an unsigned offset: beyond kBufferBytes
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float *P)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, kBufferBytes, 0x00020000);
+}
+
+template <bool kfast, bool vec>
+__device__ __forceinline__ void slab_load(Slab &s, __amdgpu_buffer_rsrc_t P, int st, int sk, int t0, int rows, int k0,
+                                          int kend, int tid)
 {
 #pragma unroll
     for (int e = 0; e < kSlabF4; ++e) {
@@ -69,30 +87,21 @@ __device__ __forceinline__ void slab_load(Slab &s, const float *__restrict__ P, 
             kk = q >> 4;        // BK k
         }
         const int gt = t0 + tt, gk = k0 + kk;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (vec) {
-            const bool in = kfast ? (gt < rows && gk + 3 < kend) : (gk < kend && gt + 3 < rows);
-            if (in) {
-                r = *reinterpret_cast<const float4 *>(P + gt * st + gk * sk);
-            } else {  // ragged edge: element-wise
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int g_t = kfast ? gt : gt + i, g_k = kfast ? gk + i : gk;
-                    if (g_t < rows && g_k < kend) t[i] = P[g_t * st + g_k * sk];
-                }
-                r = make_float4(t[0], t[1], t[2], t[3]);
-            }
+            // the host picks `vec` only when the extent along the contiguous axis is a multiple of 4, so a float4
+            // is either wholly inside or wholly outside
+            const int off = (gt < rows && gk < kend) ? (gt * st + gk * sk) * 4 : kOutside;
+            s.v[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(P, off, 0, 0));
         } else {
-            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            float t[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int g_t = kfast ? gt : gt + i, g_k = kfast ? gk + i : gk;
-                if (g_t < rows && g_k < kend) t[i] = P[g_t * st + g_k * sk];
+                const int off = (g_t < rows && g_k < kend) ? (g_t * st + g_k * sk) * 4 : kOutside;
+                t[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(P, off, 0, 0));
             }
-            r = make_float4(t[0], t[1], t[2], t[3]);
+            s.v[e] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        s.v[e] = r;
     }
 }
 
@@ -117,10 +126,83 @@ __device__ __forceinline__ void slab_store(const Slab &s, float *__restrict__ ld
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
+// Workgroup -> (n tile, m tile, K slice).  Consecutive workgroup ids land on consecutive XCDs (8 of them, each
+// with its own L2), so the id is read as (xcd, slot) and everything that shares operand bytes gets the same xcd:
+//  * split-K products (dense forward: 16 tiles x 16 slices of x and W): an XCD owns whole K slices, so each byte
+//    of both operands crosses the fabric once instead of once per XCD that holds a tile of its row / column block;
+//  * unsplit products (dense dW / dX: 4 x 61 tiles, the 4 MB operand indexed by the long axis): the tiles along
+//    the short axis, which all read the same block of the big operand, share an XCD.
+// The grid is padded to a multiple of 8 per group; padded ids return at once.
+constexpr int kXcds = 8;
+struct TileId {
+    int tm, tn, z;
+    bool live;
+};
+__device__ __forceinline__ TileId tile_of(int id, int gm, int gn, int split)
 {
-    __shared__ __align__(16) float s_a[TILE_WORDS];
-    __shared__ __align__(16) float s_b[TILE_WORDS];
+    const int xcd = id % kXcds, slot = id / kXcds;
+    TileId t;
+    if (split > 1) {
+        const int per = (split + kXcds - 1) / kXcds;  // K slices per XCD
+        t.z = xcd * per + slot % per;
+        const int tile = slot / per;
+        t.tn = tile % gn;
+        t.tm = tile / gn;
+        t.live = t.z < split && t.tm < gm;
+    } else if (gn >= gm) {
+        t.z = 0;
+        t.tm = slot % gm;
+        t.tn = xcd + kXcds * (slot / gm);
+        t.live = t.tn < gn;
+    } else {
+        t.z = 0;
+        t.tn = slot % gn;
+        t.tm = xcd + kXcds * (slot / gn);
+        t.live = t.tm < gm;
+    }
+    return t;
+}
+inline int tile_grid(int gm, int gn, int split)
+{
+    if (split > 1) return kXcds * ((split + kXcds - 1) / kXcds) * gm * gn;
+    const int lo = gn >= gm ? gm : gn, hi = gn >= gm ? gn : gm;
+    return kXcds * ((hi + kXcds - 1) / kXcds) * lo;
+}
+
+// DEPTH operand slabs are in flight in registers per thread (the loads of slab s + DEPTH are issued when slab s
+// is consumed): with one slab ahead a workgroup's K chain ran at the load latency, 1.85 us per 32-deep slab against
+// 0.43 us of MFMA work.  The LDS tile is double-buffered, so a slab costs one barrier.
+#ifndef PPO_TUNE_GEMM_DEPTH
+#define PPO_TUNE_GEMM_DEPTH 4
+#endif
+constexpr int DEPTH = PPO_TUNE_GEMM_DEPTH;
+
+// Diagnostic build only (tools/gemm_tune -DPPO_TUNE_GEMM_STAMPS): s_memtime at the phase boundaries of wave 0 of
+// every workgroup, into a buffer nothing else reads.
+#ifdef PPO_TUNE_GEMM_STAMPS
+__device__ unsigned long long ppo_gemm_stamps[1024 * 8];
+#define PPO_GSTAMP(slot)                                                                          \
+    do {                                                                                          \
+        unsigned long long t_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) ppo_gemm_stamps[blockIdx.x * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define PPO_GSTAMP(slot)
+#endif
+static_assert(DEPTH % 2 == 0, "the LDS buffer of a slab is its slot's parity");
+
+// a_kfast / b_kfast: which axis of each operand is contiguous in memory (k, or the tile axis); vec: both operands
+// can be fetched with aligned float4 loads
+template <bool a_kfast, bool b_kfast, bool vec>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int gn)
+{
+    __shared__ __align__(16) float s_a[2][TILE_WORDS];
+    __shared__ __align__(16) float s_b[2][TILE_WORDS];
+    const TileId t = tile_of(blockIdx.x, gm, gn, p.split);
+    if (!t.live) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -128,9 +210,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
     const int g = lane >> 4;
     const int wm = (wave >> 1) * 32;
     const int wn = (wave & 1) * 32;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.k_per_slice;
+    const int m0 = t.tm * BM;
+    const int n0 = t.tn * BN;
+    const int kbeg = t.z * p.k_per_slice;
     const int kend = min(p.K, kbeg + p.k_per_slice);
 
     f32x4 acc[2][2];
@@ -139,60 +221,140 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bool a_kfast = p.a_sk == 1;
-    const bool b_kfast = p.b_sk == 1;
-    Slab ra, rb;
-    if (kbeg < kend) {
-        slab_load(ra, p.A, p.a_sm, p.a_sk, a_kfast, p.vec_a, m0, p.M, kbeg, kend, tid);
-        slab_load(rb, p.B, p.b_sn, p.b_sk, b_kfast, p.vec_b, n0, p.N, kbeg, kend, tid);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();  // everyone is done reading the previous slab
-        slab_store(ra, s_a, a_kfast, p.relu_a, tid);
-        slab_store(rb, s_b, b_kfast, p.relu_b, tid);
+    // The K slice is walked in groups of DEPTH slabs, rounded up: slabs past kend read zeros through the range
+    // check (no memory traffic, a few idle MFMAs), which keeps every load of the main loop unconditional - with a
+    // load that may or may not have been issued the compiler has to wait as if it had not, i.e. for almost everything.
+    const int nslabs = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    const int ngroups = (nslabs + DEPTH - 1) / DEPTH;
+    const __amdgpu_buffer_rsrc_t bufA = operand_rsrc(p.A), bufB = operand_rsrc(p.B);
+    Slab ra[DEPTH], rb[DEPTH];
+
+    auto fetch = [&](int d, int slab) {
+        slab_load<a_kfast, vec>(ra[d], bufA, (int)p.a_sm, (int)p.a_sk, m0, p.M, kbeg + slab * BK, kend, tid);
+        slab_load<b_kfast, vec>(rb[d], bufB, (int)p.b_sn, (int)p.b_sk, n0, p.N, kbeg + slab * BK, kend, tid);
+    };
+    auto stage = [&](int d) {
+        // buffer d & 1 was last read two slabs ago; every wave finished that before the previous slab's barrier
+        slab_store(ra[d], s_a[d & 1], a_kfast, p.relu_a, tid);
+        slab_store(rb[d], s_b[d & 1], b_kfast, p.relu_b, tid);
         __syncthreads();
-        if (k0 + BK < kend) {  // fetch the next slab while the MFMAs run
-            slab_load(ra, p.A, p.a_sm, p.a_sk, a_kfast, p.vec_a, m0, p.M, k0 + BK, kend, tid);
-            slab_load(rb, p.B, p.b_sn, p.b_sk, b_kfast, p.vec_b, n0, p.N, k0 + BK, kend, tid);
-        }
+    };
+    auto multiply = [&](int d) {
+        // every operand read of the slab is issued before its first MFMA (32 registers): read-then-multiply per K
+        // step left the MFMA pipe idle for an LDS round trip in each of the 8 steps (one wave per SIMD: nobody
+        // else fills the gap)
+        const float *sa = s_a[d & 1], *sb = s_b[d & 1];
+        float a[BK / 4][2], b[BK / 4][2];
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-            float a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                a[i] = a_kfast ? s_a[(wm + i * 16 + l15) * PITCH_K + ks * 4 + g]
-                               : s_a[(ks * 4 + g) * PITCH_M + wm + i * 16 + l15];
+                a[ks][i] = a_kfast ? sa[(wm + i * 16 + l15) * PITCH_K + ks * 4 + g]
+                                   : sa[(ks * 4 + g) * PITCH_M + wm + i * 16 + l15];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                b[j] = b_kfast ? s_b[(wn + j * 16 + l15) * PITCH_K + ks * 4 + g]
-                               : s_b[(ks * 4 + g) * PITCH_M + wn + j * 16 + l15];
+                b[ks][j] = b_kfast ? sb[(wn + j * 16 + l15) * PITCH_K + ks * 4 + g]
+                                   : sb[(ks * 4 + g) * PITCH_M + wn + j * 16 + l15];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[ks][i], b[ks][j], acc[i][j]);
+    };
+
+    PPO_GSTAMP(0);
+    if (ngroups > 0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, d);
+        PPO_GSTAMP(1);
+        for (int grp = 1; grp < ngroups; ++grp) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                stage(d);
+                fetch(d, grp * DEPTH + d);
+                multiply(d);
+            }
+        }
+        PPO_GSTAMP(2);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {  // last group: nothing left to fetch
+            stage(d);
+            multiply(d);
         }
     }
+    PPO_GSTAMP(3);
 
     float *C = p.C;
-    if (p.split > 1) C += (size_t)blockIdx.z * p.M * p.N;
+    if (p.split > 1) C += (size_t)t.z * p.M * p.N;
     const int64_t ldc = p.split > 1 ? p.N : p.ldc;
+    const bool finish = p.split == 1;  // bias and gate belong to whoever writes the final value
+    if (p.vec_c) {
+        // The accumulators go through LDS once so that a thread owns four consecutive columns: bias, gate and the
+        // result move as float4 (4 + 4 + 4 memory instructions per thread instead of 16 + 16 + 16 dword ones, each
+        // of which costs the CU's one memory pipe about as much as a float4 does).
+        constexpr int PITCH_C = BN + 4;
+        static_assert(BM * PITCH_C <= 2 * TILE_WORDS, "the output tile is staged in the A operand's buffers");
+        float *sc = &s_a[0][0];
+        const int row0 = tid >> 4, col = (tid & 15) * 4;
+        float4 gate[4], bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool col_in = n0 + col < p.N;  // N is a multiple of 4 here
+        if (finish && p.mask) {
+            const __amdgpu_buffer_rsrc_t bufM = operand_rsrc(p.mask);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + row0 + 16 * q;
+                const int off = (m < p.M && col_in) ? (m * (int)p.ldc + n0 + col) * 4 : kOutside;
+                gate[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bufM, off, 0, 0));
+            }
+        }
+        if (finish && p.bias && col_in) bias4 = *reinterpret_cast<const float4 *>(p.bias + n0 + col);
+        __syncthreads();  // every wave is done with the last slab
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + g * 4 + r;
-                const int n = n0 + wn + j * 16 + l15;
-                if (m < p.M && n < p.N) {
-                    float v = acc[i][j][r];
-                    if (p.split == 1) {
-                        if (p.bias) v += p.bias[n];
-                        if (p.mask) v = p.mask[m * p.ldc + n] > 0.f ? v : 0.f;
-                    }
-                    C[m * ldc + n] = v;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[(wm + i * 16 + g * 4 + r) * PITCH_C + wn + j * 16 + l15] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = row0 + 16 * q, m = m0 + row;
+            float4 v = *reinterpret_cast<const float4 *>(sc + row * PITCH_C + col);
+            if (finish) {
+                v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
+                if (p.mask) {
+                    v.x = gate[q].x > 0.f ? v.x : 0.f;
+                    v.y = gate[q].y > 0.f ? v.y : 0.f;
+                    v.z = gate[q].z > 0.f ? v.z : 0.f;
+                    v.w = gate[q].w > 0.f ? v.w : 0.f;
                 }
             }
+            if (m < p.M && col_in) *reinterpret_cast<float4 *>(C + m * ldc + n0 + col) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm + i * 16 + g * 4 + r;
+                    const int n = n0 + wn + j * 16 + l15;
+                    if (m < p.M && n < p.N) {
+                        float v = acc[i][j][r];
+                        if (finish) {
+                            if (p.bias) v += p.bias[n];
+                            if (p.mask) v = p.mask[m * p.ldc + n] > 0.f ? v : 0.f;
+                        }
+                        C[m * ldc + n] = v;
+                    }
+                }
+    }
+    PPO_GSTAMP(4);
 }
 
 __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float *__restrict__ partial, int split, int M, int N,
@@ -232,50 +394,63 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const float *__restr
 //                       (consecutive along n: coalesced B rows), partials combined through LDS in partition order.
 constexpr int kRowsMaxN = 32, kRowsMaxKPerLane = 8;
 
+// NB output columns per pass: the NB * KPL operand loads of a pass are all issued before the first use (with the
+// heads' 13 columns and K = 256 that is ONE pass of 64 loads per lane; the rolled 4-column form paid four
+// dependent load round trips and measured 14 us for 0.85 MFLOP).  The order of the additions does not depend on NB.
+template <int NB, int KPL>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs p)
 {
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (m >= p.M) return;
-    const float *a = p.A + m * p.a_sm;
-    const int kpl = (p.K + 63) / 64;  // <= kRowsMaxKPerLane
-    float av[kRowsMaxKPerLane];
+    // range-checked buffer loads (k >= K reads zero): no branch around any load
+    const __amdgpu_buffer_rsrc_t bufA = operand_rsrc(p.A), bufB = operand_rsrc(p.B);
+    bool kin[KPL];
 #pragma unroll
-    for (int i = 0; i < kRowsMaxKPerLane; ++i) {
-        const int k = lane + 64 * i;
-        float v = (i < kpl && k < p.K) ? a[k] : 0.f;
-        av[i] = p.relu_a ? fmaxf(v, 0.f) : v;
+    for (int i = 0; i < KPL; ++i) kin[i] = lane + 64 * i < p.K;
+    float av[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int off = kin[i] ? (m * (int)p.a_sm + lane + 64 * i) * 4 : kOutside;
+        av[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bufA, off, 0, 0));  // ReLU at use
     }
-    // 4 output columns per pass: their 4 * kpl loads are all issued before the first use
-    for (int n0 = 0; n0 < p.N; n0 += 4) {
-        float bv[4][kRowsMaxKPerLane];
+    for (int n0 = 0; n0 < p.N; n0 += NB) {
+        float bv[NB][KPL];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float *b = p.B + min(n0 + j, p.N - 1) * p.b_sn;
+        for (int j = 0; j < NB; ++j) {
+            const int row = min(n0 + j, p.N - 1) * (int)p.b_sn;
 #pragma unroll
-            for (int i = 0; i < kRowsMaxKPerLane; ++i) {
-                const int k = lane + 64 * i;
-                bv[j][i] = (i < kpl && k < p.K) ? b[k] : 0.f;
+            for (int i = 0; i < KPL; ++i) {
+                const int off = kin[i] ? (row + lane + 64 * i) * 4 : kOutside;
+                bv[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bufB, off, 0, 0));
             }
         }
+        // keeps the (loop-invariant) ReLU of A's row below the loads of B: hoisted above them it made the wave wait
+        // for A's row before the first load of B was issued
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int i = 0; i < KPL; ++i) asm volatile("" : "+v"(av[i]));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < kRowsMaxKPerLane; ++i) {
+            for (int i = 0; i < KPL; ++i) {
                 float x = bv[j][i];
                 if (p.relu_b) x = fmaxf(x, 0.f);
-                acc = fmaf(av[i], x, acc);
+                acc = fmaf(p.relu_a ? fmaxf(av[i], 0.f) : av[i], x, acc);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            const int n = n0 + j;
-            if (lane == 0 && n < p.N) {
-                float v = acc;
-                if (p.bias) v += p.bias[n];
-                if (p.mask) v = p.mask[m * p.ldc + n] > 0.f ? v : 0.f;
-                p.C[m * p.ldc + n] = v;
-            }
+            bv[j][0] = acc;
+        }
+        // lane j finishes column n0 + j: one bias load, one gate load and one store per wave and pass
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) v = lane == j ? bv[j][0] : v;
+        const int n = n0 + lane;
+        if (lane < NB && n < p.N) {
+            if (p.bias) v += p.bias[n];
+            if (p.mask) v = p.mask[m * p.ldc + n] > 0.f ? v : 0.f;
+            p.C[m * p.ldc + n] = v;
         }
     }
 }
@@ -335,8 +510,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     const int n = blockIdx.x * 16 + (threadIdx.x & 15);
     const int part = threadIdx.x >> 4;  // 16 row partitions
     float v = 0.f;
-    if (n < N)
-        for (int m = part; m < M; m += 16) v += X[m * ldx + n];
+    if (n < N) {
+        // rows part, part + 16, ... added in that order; eight loads in flight per trip (one per trip measured
+        // 5.4 us for a 256 x 256 sum: sixteen dependent round trips)
+        for (int m = part; m < M; m += 16 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int mm = m + 16 * u;
+                t[u] = mm < M ? X[mm * ldx + n] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+    }
     s[threadIdx.x] = v;
     __syncthreads();
     if (part == 0 && n < N) {
@@ -347,11 +534,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     }
 }
 
-inline bool vec_ok(const float *P, int64_t s_tile, int64_t s_k)
+inline bool vec_ok(const float *P, int64_t s_tile, int64_t s_k, int tile_extent, int k_extent)
 {
-    // float4 along the contiguous axis: the other stride and the base must keep 16-byte alignment
+    // float4 along the contiguous axis: the other stride and the base keep 16-byte alignment, and the extent along
+    // the contiguous axis is a multiple of 4 (no float4 straddles the edge)
     const int64_t other = s_k == 1 ? s_tile : s_k;
-    return (s_k == 1 || s_tile == 1) && other % 4 == 0 && aligned(P, 16);
+    const int extent = s_k == 1 ? k_extent : tile_extent;
+    return (s_k == 1 || s_tile == 1) && other % 4 == 0 && extent % 4 == 0 && aligned(P, 16);
 }
 
 }  // namespace
@@ -372,31 +561,64 @@ extern "C" int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu
     if (M == 0 || N == 0) return PPO_OK;
     if (!A || !B || !C) return fail(PPO_E_INVALID, "ppo_gemm_f32: null pointer");
     if (ldc < N) return fail(PPO_E_INVALID, "ppo_gemm_f32: ldc < N");
+    // the kernels address their operands with 32-bit byte offsets
+    const int64_t a_last = (int64_t)(M - 1) * a_sm + (int64_t)(K - 1) * a_sk, b_last = (int64_t)(N - 1) * b_sn + (int64_t)(K - 1) * b_sk;
+    if (K > 0 && (a_last * 4 + 16 > (int64_t)kBufferBytes || b_last * 4 + 16 > (int64_t)kBufferBytes || a_sm < 0 || a_sk < 0 ||
+                  b_sn < 0 || b_sk < 0))
+        return fail(PPO_E_INVALID, "ppo_gemm_f32: operand spans 2 GiB or more (or a negative stride); split the batch");
     hipStream_t st = as_stream(stream);
     // The choice of kernel must not depend on the batch size, or a rollout forward (batch A) and a training
     // forward (batch 256) of the same sample would round differently.  N and K of a forward product are model
     // dimensions; M is the batch unless A is read transposed (a_sm == 1: a weight-gradient product dY^T X,
     // where M is a model dimension and K the batch).
     if ((N <= 16 || K <= 16 || (M <= 16 && a_sm == 1)) && (int64_t)M * N <= (1 << 22)) {
-        GemmArgs q{A, B, C, bias, mask, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, relu_a, relu_b, K, 1, 0, 0};
+        GemmArgs q{A, B, C, bias, mask, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, relu_a, relu_b, K, 1, 0, 0, 0};
         if (N <= kRowsMaxN && a_sk == 1 && b_sk == 1 && K <= 64 * kRowsMaxKPerLane) {
-            hipLaunchKernelGGL(gemm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, q);
+            if (K <= 256 && N <= 16)
+                hipLaunchKernelGGL((gemm_rows_kernel<16, 4>), dim3((M + 3) / 4), dim3(256), 0, st, q);
+            else if (K <= 256)
+                hipLaunchKernelGGL((gemm_rows_kernel<8, 4>), dim3((M + 3) / 4), dim3(256), 0, st, q);
+            else
+                hipLaunchKernelGGL((gemm_rows_kernel<4, kRowsMaxKPerLane>), dim3((M + 3) / 4), dim3(256), 0, st, q);
             return check_launch("gemm_rows_kernel");
         }
         hipLaunchKernelGGL(gemm_small_kernel, dim3((M * N + 15) / 16), dim3(256), 0, st, q);
         return check_launch("gemm_small_kernel");
     }
     const int gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
-    // split K until two workgroups per CU are in flight (one 4-wave workgroup per CU cannot hide the operand
-    // loads of its own K chain), slices at least 64 deep
+    // Few tiles: split K into slices of kSliceK (the slice count depends on K and on the tile counts of the model
+    // dimensions only through `few`, which for a forward product x @ W^T is a property of N: a rollout forward and a
+    // training forward of the same sample must round alike whatever the batch).
+    constexpr int kSliceK = 256;
     int split = 1;
-    while (gm * gn * split < 512 && split < 32 && K / (split * 2) >= 64) split *= 2;
+    const bool few = gn * 4 <= 32;  // at most 8 column tiles: even a 2048-row batch leaves CUs idle without slicing
+    if (few && K >= 2 * kSliceK) split = std::min(32, (K + kSliceK - 1) / kSliceK);
     if (split > 1 && (!workspace || workspace_bytes < (size_t)split * M * N * sizeof(float))) split = 1;
     int kps = (K + split - 1) / split;
     kps = (kps + BK - 1) / BK * BK;
+    if (split > 1) split = (K + kps - 1) / kps;  // no empty slices
     GemmArgs p{A, B, split > 1 ? static_cast<float *>(workspace) : C, bias, mask, M, N, K, a_sm, a_sk, b_sk, b_sn,
-               ldc, relu_a, relu_b, kps, split, vec_ok(A, a_sm, a_sk) ? 1 : 0, vec_ok(B, b_sn, b_sk) ? 1 : 0};
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(gn, gm, split), dim3(256), 0, st, p);
+               ldc, relu_a, relu_b, kps, split, vec_ok(A, a_sm, a_sk, M, K) ? 1 : 0, vec_ok(B, b_sn, b_sk, N, K) ? 1 : 0, 0};
+    p.vec_c = N % 4 == 0 && ldc % 4 == 0 && aligned(C, 16) && aligned(p.C, 16) && (!bias || aligned(bias, 16)) &&
+              (!mask || (aligned(mask, 16) && (int64_t)M * ldc * 4 < (int64_t)kBufferBytes));
+    const dim3 grid(tile_grid(gm, gn, split));
+    const bool vec = p.vec_a && p.vec_b;
+    const int variant = (a_sk == 1 ? 4 : 0) | (b_sk == 1 ? 2 : 0) | (vec ? 1 : 0);
+#define PPO_GEMM_CASE(v, ak, bk, vc)                                                                  \
+    case v:                                                                                           \
+        hipLaunchKernelGGL((gemm_f32_kernel<ak, bk, vc>), grid, dim3(256), 0, st, p, gm, gn);         \
+        break;
+    switch (variant) {
+        PPO_GEMM_CASE(0, false, false, false)
+        PPO_GEMM_CASE(1, false, false, true)
+        PPO_GEMM_CASE(2, false, true, false)
+        PPO_GEMM_CASE(3, false, true, true)
+        PPO_GEMM_CASE(4, true, false, false)
+        PPO_GEMM_CASE(5, true, false, true)
+        PPO_GEMM_CASE(6, true, true, false)
+        PPO_GEMM_CASE(7, true, true, true)
+    }
+#undef PPO_GEMM_CASE
     int rc = check_launch("gemm_f32_kernel");
     if (rc) return rc;
     if (split > 1) {
