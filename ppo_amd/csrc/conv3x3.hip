@@ -285,6 +285,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             }
     };
 
+    const bool gate_off = mask_src == nullptr;
     int buf = 0;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int img = item / C::NBANDS;
@@ -324,8 +325,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
             // loop, so their memory latency hides under the MFMAs
             bool live[MT];
             float gate[MT][C::NT][4], res[MT][C::NT][4];
-            const float *mask_img = mask_src ? mask_src + img_off : nullptr;
-            const float *res_img = residual ? residual + img_off : nullptr;
+            // (range-checked buffer reads, common.h: lanes without an output element, and absent tensors, read zeros;
+            // a zero gate only ever meets an element that is not stored, or gate_off)
+            const __amdgpu_buffer_rsrc_t mask_img = buffer_of(mask_src ? mask_src + img_off : nullptr, mask_src != nullptr);
+            const __amdgpu_buffer_rsrc_t res_img = buffer_of(residual ? residual + img_off : nullptr, residual != nullptr);
             int p4[MT];  // WIDE: first of this lane's 4 pixels of tile m
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -335,11 +338,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
 #pragma unroll
                     for (int n = 0; n < C::NT; ++n) {
                         const int oi = p4[m] + (n * 16 + ch) * (H * W);
-                        const bool ok = live[m] && n * 16 + ch < COUT;
-                        const float4 gv = (mask_img && ok) ? *reinterpret_cast<const float4 *>(mask_img + oi)
-                                                           : make_float4(1.f, 1.f, 1.f, 1.f);
-                        const float4 rv = (res_img && ok) ? *reinterpret_cast<const float4 *>(res_img + oi)
-                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const int off = (live[m] && n * 16 + ch < COUT) ? oi * 4 : kOutside;
+                        const float4 gv = buffer_f32x4(mask_img, off);
+                        const float4 rv = buffer_f32x4(res_img, off);
                         gate[m][n][0] = gv.x, gate[m][n][1] = gv.y, gate[m][n][2] = gv.z, gate[m][n][3] = gv.w;
                         res[m][n][0] = rv.x, res[m][n][1] = rv.y, res[m][n][2] = rv.z, res[m][n][3] = rv.w;
                     }
@@ -352,8 +353,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
                     for (int r = 0; r < 4; ++r) {
                         const int co = n * 16 + g * 4 + r;
                         const int oi = pix[q][m] + co * (H * W);
-                        gate[m][n][r] = (mask_img && live[m] && co < COUT) ? mask_img[oi] : 1.f;
-                        res[m][n][r] = (res_img && live[m] && co < COUT) ? res_img[oi] : 0.f;
+                        const int off = (live[m] && co < COUT) ? oi * 4 : kOutside;
+                        gate[m][n][r] = buffer_f32(mask_img, off);
+                        res[m][n][r] = buffer_f32(res_img, off);
                     }
             }
             int base[MT];
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float val = ov[e] + bias_c[n];
-                            val = gate[m][n][e] > 0.f ? val : 0.f;
+                            val = (gate[m][n][e] > 0.f || gate_off) ? val : 0.f;
                             pend[m][n][e] = val + res[m][n][e];
                         }
                     }
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float val = acc[n][m][r] + bias_r[n][r];
-                        val = gate[m][n][r] > 0.f ? val : 0.f;
+                        val = (gate[m][n][r] > 0.f || gate_off) ? val : 0.f;
                         pend[m][n][r] = val + res[m][n][r];
                     }
             }

@@ -417,6 +417,28 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 // dW[o][i][tap] = sum_wg partial[wg][o][tap*CINP + i]; db[o] = sum_wg partial[wg][o][9*CINP].
 // A thread owns 4 consecutive j of one output channel (16-byte loads); 64 such quads per workgroup,
 // 4 threads per quad each summing a quarter of the slabs, combined in LDS in a fixed order.
+// Sum of one thread's partition of the slabs (slabs lo .. hi - 1 of one float4 of the [cout][jp] image): even slabs
+// into one accumulator, odd ones into another, added at the end (the order the rolled two-at-a-time loop used, so the
+// result is bit-identical to it).  All (up to 16) loads of a trip are issued before the first add - the rolled loop
+// paid a memory round trip per pair, 8 of them in a row for 256 slabs - through a range-checked buffer descriptor
+// (common.h): a slab index past hi reads zeros.
+__device__ __forceinline__ float4 slab_partition_sum(const float *slabs, int byte_off, int byte_stride, int lo, int hi, bool live)
+{
+    const __amdgpu_buffer_rsrc_t buf = buffer_of(slabs);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    for (int q = lo; q < hi; q += 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = buffer_f32x4(buf, (live && q + u < hi) ? byte_off + (q + u) * byte_stride : kOutside);
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            s0.x += v[u].x; s0.y += v[u].y; s0.z += v[u].z; s0.w += v[u].w;
+            s1.x += v[u + 1].x; s1.y += v[u + 1].y; s1.z += v[u + 1].z; s1.w += v[u + 1].w;
+        }
+    }
+    return make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+}
+
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ partial, int n_slabs,
                                                                    int cout, int cin, int cinp, int jp,
                                                                    float *__restrict__ dw, float *__restrict__ db,
@@ -430,25 +452,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *
     const int co = live ? idx / q4 : 0;
     const int j0 = live ? (idx % q4) * 4 : 0;
     const size_t stride = (size_t)cout * jp;
-    const float *p = partial + (size_t)co * jp + j0;
     const int per = (n_slabs + 15) / 16;
     const int lo = part * per;
     const int hi = lo + per < n_slabs ? lo + per : n_slabs;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    if (live) {
-        int q = lo;
-        for (; q + 2 <= hi; q += 2) {
-            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
-            const float4 b = *reinterpret_cast<const float4 *>(p + (size_t)(q + 1) * stride);
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-        }
-        for (; q < hi; ++q) {
-            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        }
-    }
-    s[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    s[threadIdx.x] = slab_partition_sum(partial, (co * jp + j0) * 4, (int)stride * 4, lo, hi, live);
     __syncthreads();
     if (part == 0 && live) {
         float sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -504,25 +511,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_jobs_kernel(ReduceJo
     const int co = live ? idx / q4 : 0;
     const int j0 = live ? (idx % q4) * 4 : 0;
     const size_t stride = (size_t)cout * jp;
-    const float *p = job.slabs + (size_t)co * jp + j0;
     const int per = (n_slabs + 15) / 16;
     const int lo = part * per;
     const int hi = lo + per < n_slabs ? lo + per : n_slabs;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    if (live) {
-        int q = lo;
-        for (; q + 2 <= hi; q += 2) {
-            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
-            const float4 b = *reinterpret_cast<const float4 *>(p + (size_t)(q + 1) * stride);
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-        }
-        for (; q < hi; ++q) {
-            const float4 a = *reinterpret_cast<const float4 *>(p + (size_t)q * stride);
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        }
-    }
-    s[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    s[threadIdx.x] = slab_partition_sum(job.slabs, (co * jp + j0) * 4, (int)stride * 4, lo, hi, live);
     __syncthreads();
     if (part == 0 && live) {
         float sum[4] = {0.f, 0.f, 0.f, 0.f};

@@ -158,31 +158,32 @@ __device__ __forceinline__ void dy_pooled_load(const float *__restrict__ g, cons
                                                int y0, int tid, PooledRaw (&raw)[PooledMap<C, H, W, TR, NWAVES>::Q])
 {
     using M = PooledMap<C, H, W, TR, NWAVES>;
+    // Range-checked buffer reads (common.h) from this image's planes: a window beyond the map's right / bottom edge,
+    // or a thread without a task, reads gradient 0 (and argmax 0, which then selects nothing but that 0).  Written
+    // as `if (right) x = g[..]` every load was a branch with a full memory wait behind it, and the point of this
+    // function - the gather of the NEXT item in flight during the K loop - was lost.
+    const size_t img_base = (size_t)img * C * M::HO * M::WO;
+    const __amdgpu_buffer_rsrc_t gb = buffer_of(g + img_base), ab = buffer_of(argmax + img_base);
 #pragma unroll
     for (int q = 0; q < M::Q; ++q) {
         const int b = tid + q * NWAVES * 64;
-        PooledRaw r{make_float2(0.f, 0.f), make_float2(0.f, 0.f), 0.f, 0.f, 0xffffu, 0xffffu, -1, -1};
-        if (b < M::NTASK) {
-            const int c = b / (M::JB * M::KP), rem = b % (M::JB * M::KP);
-            const int jb = rem / M::KP, k0 = 2 * (rem % M::KP);
-            const int j = y0 / 2 + jb;
-            const size_t t = ((size_t)(img * C + c) * M::HO + j) * M::WO + k0;
-            const bool right = k0 + 2 < M::WO, down = j + 1 < M::HO;
-            r.ga = *reinterpret_cast<const float2 *>(g + t);
-            r.aa = *reinterpret_cast<const unsigned short *>(argmax + t);
-            if (right) {
-                r.ga2 = g[t + 2];
-                r.ta2 = argmax[t + 2];
-            }
-            if (down) {
-                r.gb = *reinterpret_cast<const float2 *>(g + t + M::WO);
-                r.ab = *reinterpret_cast<const unsigned short *>(argmax + t + M::WO);
-                if (right) {
-                    r.gb2 = g[t + M::WO + 2];
-                    r.tb2 = argmax[t + M::WO + 2];
-                }
-            }
-        }
+        const bool task = b < M::NTASK;
+        const int c = b / (M::JB * M::KP), rem = b % (M::JB * M::KP);
+        const int jb = rem / M::KP, k0 = 2 * (rem % M::KP);
+        const int j = y0 / 2 + jb;
+        const int t = (c * M::HO + j) * M::WO + k0;
+        const bool right = task && k0 + 2 < M::WO, down = task && j + 1 < M::HO;
+        const int o_a = task ? t : -1, o_a2 = right ? t + 2 : -1, o_b = down ? t + M::WO : -1,
+                  o_b2 = (down && right) ? t + M::WO + 2 : -1;
+        PooledRaw r;
+        r.ga = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gb, o_a < 0 ? kOutside : o_a * 4, 0, 0));
+        r.gb = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gb, o_b < 0 ? kOutside : o_b * 4, 0, 0));
+        r.ga2 = buffer_f32(gb, o_a2 < 0 ? kOutside : o_a2 * 4);
+        r.gb2 = buffer_f32(gb, o_b2 < 0 ? kOutside : o_b2 * 4);
+        r.aa = __builtin_amdgcn_raw_buffer_load_b16(ab, o_a < 0 ? kOutside : o_a, 0, 0);
+        r.ab = __builtin_amdgcn_raw_buffer_load_b16(ab, o_b < 0 ? kOutside : o_b, 0, 0);
+        r.ta2 = __builtin_amdgcn_raw_buffer_load_b8(ab, o_a2 < 0 ? kOutside : o_a2, 0, 0);
+        r.tb2 = __builtin_amdgcn_raw_buffer_load_b8(ab, o_b2 < 0 ? kOutside : o_b2, 0, 0);
         raw[q] = r;
     }
 }

@@ -57,19 +57,10 @@ struct Slab {
     float4 v[kSlabF4];
 };
 
-// Operands are read through buffer descriptors: an element outside the matrix gets the offset kOutside, which the
-// hardware range check turns into zeros.  (A predicated global load - `in ? P[i] : 0`, however it is spelled - is
-// compiled to a branch around the load, and the wait-count bookkeeping at every such join falls back to vmcnt(0):
-// the whole prefetch serialised, 1.5 us per slab.)  Offsets are 32-bit byte offsets: the host checks the operands
-// are below kBufferBytes.
-constexpr uint32_t kBufferBytes = 0x80000000u;
-constexpr int kOutside = -16;  // 0xfffffff0 as an unsigned offset: beyond kBufferBytes
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float *P)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, kBufferBytes, 0x00020000);
-}
+// Operands are read through buffer descriptors (common.h: a predicated global load serialises the whole prefetch,
+// 1.5 us per slab): an element outside the matrix gets the offset kOutside, which the hardware range check turns into
+// zeros.  Offsets are 32-bit byte offsets: the host checks the operands are below kBufferBytes.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float *P) { return buffer_of(P); }
 
 template <bool kfast, bool vec>
 __device__ __forceinline__ void slab_load(Slab &s, __amdgpu_buffer_rsrc_t P, int st, int sk, int t0, int rows, int k0,
@@ -91,14 +82,14 @@ __device__ __forceinline__ void slab_load(Slab &s, __amdgpu_buffer_rsrc_t P, int
             // the host picks `vec` only when the extent along the contiguous axis is a multiple of 4, so a float4
             // is either wholly inside or wholly outside
             const int off = (gt < rows && gk < kend) ? (gt * st + gk * sk) * 4 : kOutside;
-            s.v[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(P, off, 0, 0));
+            s.v[e] = buffer_f32x4(P, off);
         } else {
             float t[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int g_t = kfast ? gt : gt + i, g_k = kfast ? gk + i : gk;
                 const int off = (g_t < rows && g_k < kend) ? (g_t * st + g_k * sk) * 4 : kOutside;
-                t[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(P, off, 0, 0));
+                t[i] = buffer_f32(P, off);
             }
             s.v[e] = make_float4(t[0], t[1], t[2], t[3]);
         }
@@ -307,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + row0 + 16 * q;
                 const int off = (m < p.M && col_in) ? (m * (int)p.ldc + n0 + col) * 4 : kOutside;
-                gate[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bufM, off, 0, 0));
+                gate[q] = buffer_f32x4(bufM, off);
             }
         }
         if (finish && p.bias && col_in) bias4 = *reinterpret_cast<const float4 *>(p.bias + n0 + col);
@@ -412,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs p)
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
         const int off = kin[i] ? (m * (int)p.a_sm + lane + 64 * i) * 4 : kOutside;
-        av[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bufA, off, 0, 0));  // ReLU at use
+        av[i] = buffer_f32(bufA, off);  // ReLU at use
     }
     for (int n0 = 0; n0 < p.N; n0 += NB) {
         float bv[NB][KPL];
@@ -422,7 +413,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs p)
 #pragma unroll
             for (int i = 0; i < KPL; ++i) {
                 const int off = kin[i] ? (row + lane + 64 * i) * 4 : kOutside;
-                bv[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bufB, off, 0, 0));
+                bv[j][i] = buffer_f32(bufB, off);
             }
         }
         // keeps the (loop-invariant) ReLU of A's row below the loads of B: hoisted above them it made the wave wait

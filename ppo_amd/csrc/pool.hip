@@ -67,29 +67,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
     const bool has_oy1 = (iy & 1) && (oy0 + 1 < Ho);
     // columns: ix0 = 2k is tap col 1 of ox = k; ix1 = 2k+1 is tap col 2 of ox = k and tap col 0 of ox = k+1
     const bool has_ox1 = (k + 1 < Wo);
+    // All four (argmax, gradient) pairs are read unconditionally through range-checked descriptors (common.h): a
+    // window that does not exist reads gradient 0.  (Reading the gradient only when the argmax matched made every
+    // load a branch with a full memory wait behind it.)  The additions keep the order of the conditional form.
+    const __amdgpu_buffer_rsrc_t gb = buffer_of(g), ab = buffer_of(a);
+    const int i00 = oy0 * Wo + k, i10 = i00 + Wo;
+    const int o00 = i00, o01 = has_ox1 ? i00 + 1 : -1, o10 = has_oy1 ? i10 : -1, o11 = (has_oy1 && has_ox1) ? i10 + 1 : -1;
+    const int t00 = __builtin_amdgcn_raw_buffer_load_b8(ab, o00, 0, 0);
+    const int t01 = __builtin_amdgcn_raw_buffer_load_b8(ab, o01 < 0 ? kOutside : o01, 0, 0);
+    const int t10 = __builtin_amdgcn_raw_buffer_load_b8(ab, o10 < 0 ? kOutside : o10, 0, 0);
+    const int t11 = __builtin_amdgcn_raw_buffer_load_b8(ab, o11 < 0 ? kOutside : o11, 0, 0);
+    const float g00 = buffer_f32(gb, o00 * 4);
+    const float g01 = buffer_f32(gb, o01 < 0 ? kOutside : o01 * 4);
+    const float g10 = buffer_f32(gb, o10 < 0 ? kOutside : o10 * 4);
+    const float g11 = buffer_f32(gb, o11 < 0 ? kOutside : o11 * 4);
     float s0 = 0.f, s1 = 0.f;
-    {
-        const int i00 = oy0 * Wo + k;
-        const int tap = a[i00];
-        const float gv = g[i00];
-        if (tap == ky0 * 3 + 1) s0 += gv;
-        if (tap == ky0 * 3 + 2) s1 += gv;
-        if (has_ox1) {
-            const int tap1 = a[i00 + 1];
-            if (tap1 == ky0 * 3 + 0) s1 += g[i00 + 1];
-        }
-    }
-    if (has_oy1) {
-        const int i10 = (oy0 + 1) * Wo + k;
-        const int tap = a[i10];
-        const float gv = g[i10];
-        if (tap == 1) s0 += gv;
-        if (tap == 2) s1 += gv;
-        if (has_ox1) {
-            const int tap1 = a[i10 + 1];
-            if (tap1 == 0) s1 += g[i10 + 1];
-        }
-    }
+    s0 += t00 == ky0 * 3 + 1 ? g00 : 0.f;
+    s1 += t00 == ky0 * 3 + 2 ? g00 : 0.f;
+    s1 += t01 == ky0 * 3 + 0 ? g01 : 0.f;
+    s0 += t10 == 1 ? g10 : 0.f;
+    s1 += t10 == 2 ? g10 : 0.f;
+    s1 += t11 == 0 ? g11 : 0.f;
     float *dst = din + pl * H * W + iy * W + 2 * k;
     if (PAIR_STORE) {
         *reinterpret_cast<float2 *>(dst) = make_float2(s0, s1);

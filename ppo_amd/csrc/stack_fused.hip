@@ -121,14 +121,16 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailA
             // after the K loop
             float gate[BACKWARD ? MT : 1][NT][4];
             if constexpr (BACKWARD) {
-                const float *mask = a.mask[layer] + img_off;
+                // range-checked buffer reads (common.h): a predicated load is a branch plus a full memory wait each
+                const __amdgpu_buffer_rsrc_t mask = buffer_of(a.mask[layer] + img_off);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            gate[m][n][r] = pix[m] < S::NPIX ? mask[((n0 + n) * 16 + g * 4 + r) * (H * W) + pix[m]] : 1.f;
+                            gate[m][n][r] = buffer_f32(mask, pix[m] < S::NPIX ? (((n0 + n) * 16 + g * 4 + r) * (H * W) + pix[m]) * 4
+                                                                              : kOutside);  // unused beyond the map
             }
 
             __syncthreads();  // the source map is complete (DMA landed / previous epilogue's LDS writes)
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(1024) void stack_shift_kernel(StackTailArgs a)
             const float *res = odd ? (layer == 1 ? a.in : a.save[1]) + img_off : nullptr;
             const float *mask = BACKWARD ? a.mask[layer] + img_off : nullptr;
             float *save = a.save[layer] ? a.save[layer] + img_off : nullptr;
+            const __amdgpu_buffer_rsrc_t mask_b = buffer_of(mask, mask != nullptr), res_b = buffer_of(res, res != nullptr);
             const int in_row = 5 - layer;  // plane row of this layer's input row y = 0
 
             // state a band carries from its K half-step to its epilogue half-step
@@ -372,8 +375,10 @@ __global__ __launch_bounds__(1024) void stack_shift_kernel(StackTailArgs a)
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
                             const bool live = p4[m] < S::NPIX;  // a quad is whole or absent (NPIX % 4 == 0)
-                            gate4[m] = (mask && live) ? *reinterpret_cast<const float4 *>(mask + chan_off + p4[m]) : make_float4(1.f, 1.f, 1.f, 1.f);
-                            res4[m] = (res && live) ? *reinterpret_cast<const float4 *>(res + chan_off + p4[m]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            // range-checked buffer reads (common.h); an absent tensor reads zeros
+                            const int off = live ? (chan_off + p4[m]) * 4 : kOutside;
+                            if constexpr (BACKWARD) gate4[m] = buffer_f32x4(mask_b, off);
+                            res4[m] = buffer_f32x4(res_b, off);
                         }
                         int base[MT];
 #pragma unroll
@@ -568,13 +573,15 @@ __device__ __forceinline__ void resident_conv(float *smem, int src_off, int dst_
         for (int r = 0; r < 4; ++r) bias_r[n][r] = (GATED || !bias) ? 0.f : bias[(n0 + n) * 16 + g * 4 + r];
     float gate[GATED ? MT : 1][NT][4];
     if constexpr (GATED) {
+        const __amdgpu_buffer_rsrc_t mask_b = buffer_of(mask);  // range-checked reads (common.h)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    gate[m][n][r] = lm.pix[m] < H * W ? mask[((n0 + n) * 16 + g * 4 + r) * (H * W) + lm.pix[m]] : 1.f;
+                    gate[m][n][r] = buffer_f32(mask_b, lm.pix[m] < H * W ? (((n0 + n) * 16 + g * 4 + r) * (H * W) + lm.pix[m]) * 4
+                                                                         : kOutside);  // unused beyond the map
     }
 
     __syncthreads();  // the source map is complete
