@@ -669,6 +669,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     const int wave = tid >> 6;
     const int l15 = lane & 15;
     const int g = lane >> 4;
+    PPO_STAMP(t_entry)
 
     // weights -> registers through LDS (see conv3x3_kernel)
     constexpr int KS = 9 * (C::CINP / 4);
@@ -743,6 +744,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     };
     if (!DMA && (int)blockIdx.x < n_items) prefetch(blockIdx.x);
 
+    PPO_STAMP(t_loop)
+    PPO_STAMP_ADD(7, t_loop, t_entry)  // prologue: weights, zeroing, first prefetch issue
     constexpr int GROUPS = (C::MTILES + MT - 1) / MT;
     constexpr int NGW = (GROUPS + kWaves - 1) / kWaves;
     int buf = 0;
@@ -887,25 +890,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
             if (sub < RPW && co < COUT && pr < pr_n) {
                 const float *src = s_out + co * C::OPLANE + 2 * pr * W + 2 * xo - 1;  // window origin (cr = 2 pr, ix = 2 xo - 1)
                 const int yo = yo0 + pr;
-                float best = -INFINITY;
-                int best_tap = 0;
-                bool found = false;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const bool row_ok = (ky == 0) ? yo > 0 : (ky == 1 ? true : 2 * yo + 1 < H);
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const bool col_ok = (kx == 0) ? xo > 0 : (kx == 1 ? true : 2 * xo + 1 < W);
-                        if (row_ok && col_ok) {
-                            const float v = src[ky * W + kx];
-                            if (!found || v > best || v != v) {
-                                best = v;
-                                best_tap = ky * 3 + kx;
-                                found = true;
-                            }
-                        }
-                    }
-                }
+                float best;
+                int best_tap;
+                pool_window_lds(src, W, yo > 0, 2 * yo + 1 < H, xo > 0, 2 * xo + 1 < W, best, best_tap);
                 const size_t oi = ((size_t)(img * COUT + co) * C::HO + yo) * C::WO + xo;
                 out[oi] = best;
                 if (argmax) argmax[oi] = (uint8_t)best_tap;
@@ -921,6 +908,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
         if (lane == 0) { PPO_STAMP_ADD(5, 1ull, 0ull) }
         if constexpr (DMA) buf ^= 1;
     }
+    PPO_STAMP(t_exit)
+    PPO_STAMP_ADD(6, t_exit, t_entry)  // wave lifetime
 }
 
 template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE, bool PACKED>

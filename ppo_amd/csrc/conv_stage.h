@@ -462,4 +462,35 @@ __device__ __forceinline__ void zero_lds(float *__restrict__ s, int tid)
     for (int i = tid; i < WORDS; i += NTHREADS) s[i] = 0.f;
 }
 
+// 3x3 max-pool window from LDS: src -> tap (0, 0), rows `stride` floats apart; r0 / r2 (c0 / c2): the window's first /
+// last row (column) lies inside the map (the middle ones always do).  Ties go to the first tap in row-major order,
+// NaN propagates (F.max_pool2d).  All nine taps are read before the first compare, valid or not - the caller
+// guarantees the addresses are inside the LDS allocation: `if (valid) v = src[..]` made every tap a branch with a
+// full LDS wait behind it, nine round trips in a row per output.
+__device__ __forceinline__ void pool_window_lds(const float *src, int stride, bool r0, bool r2, bool c0, bool c2, float &best,
+                                                int &best_tap)
+{
+    float v[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v[ky][kx] = src[ky * stride + kx];
+    best = -INFINITY;
+    best_tap = 0;
+    bool found = false;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const bool row_ok = ky == 0 ? r0 : (ky == 1 ? true : r2);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const bool ok = row_ok && (kx == 0 ? c0 : (kx == 1 ? true : c2));
+            const float x = v[ky][kx];
+            const bool take = ok && (!found || x > best || x != x);
+            best = take ? x : best;
+            best_tap = take ? ky * 3 + kx : best_tap;
+            found = found || ok;
+        }
+    }
+}
+
 }  // namespace ppo

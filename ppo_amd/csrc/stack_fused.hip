@@ -731,25 +731,9 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_full_kernel(StackFullA
                 const int co = u / HO, yo = u % HO;
                 if (sub < RPW && co < C) {
                     const float *src = smem + B_OFF + co * SI::PLANE + SI::G + WI + (2 * yo - 1) * WI + 2 * xo - 1;
-                    float best = -INFINITY;
-                    int best_tap = 0;
-                    bool found = false;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const bool row_ok = (ky == 0) ? yo > 0 : (ky == 1 ? true : 2 * yo + 1 < HI);
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const bool col_ok = (kx == 0) ? xo > 0 : (kx == 1 ? true : 2 * xo + 1 < WI);
-                            if (row_ok && col_ok) {
-                                const float v = src[ky * WI + kx];
-                                if (!found || v > best || v != v) {
-                                    best = v;
-                                    best_tap = ky * 3 + kx;
-                                    found = true;
-                                }
-                            }
-                        }
-                    }
+                    float best;
+                    int best_tap;
+                    pool_window_lds(src, WI, yo > 0, 2 * yo + 1 < HI, xo > 0, 2 * xo + 1 < WI, best, best_tap);
                     smem[X_OFF + co * SO::PLANE + SO::G + WO + yo * WO + xo] = best;
                     const size_t oi = out_img + ((size_t)co * HO + yo) * WO + xo;
                     if (a.pooled) a.pooled[oi] = best;

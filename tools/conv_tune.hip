@@ -110,6 +110,12 @@ int main(int argc, char **argv)
                 const double n = (double)st[5];
                 printf("    per item-wave cycles: barrier+stage %.0f | group prologue %.0f | K loop %.0f | compute section %.0f | item %.0f  (item-waves %.0f)\n",
                        st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, n);
+                if (which == 3) {
+                    size_t waves = 0;
+                    for (size_t i = 6; i < all.size(); i += 8) waves += all[i] != 0;
+                    printf("    conv+pool per wave: prologue %.0f | lifetime %.0f cycles (%.1f us at 2.36 GHz)   (%zu waves per launch)\n",
+                           (double)st[7] / waves, (double)st[6] / waves, (double)st[6] / waves / 2360.0, waves);
+                }
                 if (which == 2 || which == 4)
                     printf("    wgrad per wave: prologue %.0f | fold+slab %.0f | whole kernel %.0f   (waves %d, items per wave %.1f)\n",
                            st[6] / 2048.0, st[7] / 2048.0, st[3] / 2048.0, 2048, n / 2048.0);
