@@ -204,6 +204,18 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailA
             // during an odd layer, and the next layer's readers wait at its barrier.
             float *dst = smem + (odd ? 0 : S::LDS_MAP);
             float *save = a.save[layer];
+            // the block input of an odd layer is read for ALL of the lane's elements before the first of them is
+            // overwritten (only this lane touches these positions): read-add-write per element was one LDS round
+            // trip after another, the compiler cannot move a read above the previous element's write
+            __builtin_amdgcn_sched_barrier(0);  // not hoisted into the K loop (register pressure)
+            float skip[MT][NT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        skip[m][n][r] = odd ? smem[((n0 + n) * 16 + g * 4 + r) * PLANE + G + W + (pix[m] < S::NPIX ? pix[m] : 0)] : 0.f;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if (pix[m] < S::NPIX) {
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailA
                             const int lo = co * PLANE + G + W + pix[m];
                             float val = acc[n][m][r] + bias_r[n][r];
                             if constexpr (BACKWARD) val = gate[m][n][r] > 0.f ? val : 0.f;
-                            if (odd) val = val + smem[lo];
+                            if (odd) val = val + skip[m][n][r];
                             dst[lo] = val;
                             if (save) save[img_off + (size_t)co * (H * W) + pix[m]] = val;
                         }
