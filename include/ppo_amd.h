@@ -213,6 +213,8 @@ int ppo_maxpool3x3s2_backward_f32(const float *dout, const uint8_t *argmax, floa
  * relu_a / relu_b: apply max(.,0) to that operand on load.  bias [N], mask [M,ldc] nullable;
  * mask gates the result: C = mask > 0 ? C : 0 (ReLU backward).  workspace (nullable): split-K
  * scratch of ppo_gemm_workspace_bytes(M,N,K); without it the kernel runs unsplit.
+ * Strides are non-negative; each operand must span less than 2 GiB (the kernels address it with 32-bit byte
+ * offsets through a range-checked buffer descriptor) - PPO_E_INVALID otherwise: split the batch.
  * Replaces torch.nn.Linear forward/backward at rl/models.py:84,98,364-366,470-506.
  */
 size_t ppo_gemm_workspace_bytes(int M, int N, int K);

@@ -930,6 +930,11 @@ int launch_conv_pool_impl(const void *in, const float *w, const float *bias, flo
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, kLdsBytes);
         if (e != hipSuccess) return fail(PPO_E_HIP, "conv3x3_pool: occupancy query: %s", hipGetErrorString(e));
         wg_per_cu = nb < 1 ? 1 : (nb > 3 ? 3 : nb);
+#ifdef PPO_TUNE_CP_WG  // tools/conv_tune experiment build only: force the grid multiple and report what the runtime said
+        fprintf(stderr, "conv3x3_pool<%d,%d,%d>: occupancy query %d workgroups per CU, LDS %zu B; forcing %d\n", CIN, COUT, H, nb,
+                kLdsBytes, PPO_TUNE_CP_WG);
+        wg_per_cu = PPO_TUNE_CP_WG;
+#endif
     }
     const int n_items = n_images * C::NBANDS;
     int grid = 256 * wg_per_cu;

@@ -218,6 +218,39 @@ def test_gemm_exact_on_integers_asymmetric():
     assert torch.equal(gemm(At, 1, M, 0, B, N, 1, 0, None, None, M, N, K), A @ B)
 
 
+@pytest.mark.parametrize("M,N,K", [(70, 45, 37), (130, 260, 1030), (64, 64, 256), (257, 36, 777), (33, 72, 4100)])
+@pytest.mark.parametrize("layout", ["kk", "kt", "tk", "tt"])
+def test_gemm_ragged_shapes_every_operand_layout(M, N, K, layout):
+    """Every (k-contiguous | tile-contiguous) operand layout of the MFMA kernel on shapes that are not multiples of the
+    64 x 64 x 32 tile or of 4: the scalar operand path (extent % 4 != 0), zero-padded K groups, the K-sliced form with a
+    short last slice (K >= 512, N <= 512), bias + gate with and without the float4 epilogue.  Integer data: exact."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randint(-2, 3, (M, K), generator=g).float().to(DEV)
+    B = torch.randint(-2, 3, (K, N), generator=g).float().to(DEV)
+    bias = torch.randint(-4, 5, (N,), generator=g).float().to(DEV)
+    mask = torch.randint(-1, 2, (M, N), generator=g).float().to(DEV)
+    a_args = (A, K, 1) if layout[0] == "k" else (A.t().contiguous(), 1, M)          # [M, K] or stored [K, M]
+    b_args = (B.t().contiguous(), 1, K) if layout[1] == "k" else (B, N, 1)          # stored [N, K] or [K, N]
+    want = (torch.relu(A) @ B + bias) * (mask > 0)
+    got = gemm(a_args[0], a_args[1], a_args[2], 1, b_args[0], b_args[1], b_args[2], 0, bias, mask, M, N, K)
+    assert torch.equal(got, want)
+    assert torch.equal(gemm(a_args[0], a_args[1], a_args[2], 0, b_args[0], b_args[1], b_args[2], 0, None, None, M, N, K,
+                            use_ws=False), A @ B)
+
+
+def test_gemm_rejects_operands_of_2_gib_and_zero_k():
+    """32-bit byte offsets inside the kernels: an operand that spans 2 GiB or more is refused (PPO_E_INVALID), nothing
+    is launched.  K = 0 writes the bias (an empty sum)."""
+    lib = _lib.load()
+    A = torch.zeros(8, device=DEV)
+    C = torch.zeros(4, 4, device=DEV)
+    rc = lib.ppo_gemm_f32(_p(A), 1 << 29, 1, 0, _p(A), 1, 1 << 29, 0, None, None, _p(C), 4, 4, 4, 2, None, 0, _st())
+    assert rc != 0 and b"2 GiB" in lib.ppo_last_error()
+    bias = torch.arange(4.0, device=DEV)
+    out = gemm(A, 0, 1, 0, A, 1, 0, 0, bias, None, 4, 4, 0)
+    assert torch.equal(out, bias.expand(4, 4))
+
+
 # ------------------------------------------------------------------ policy act / PPO loss
 @pytest.mark.parametrize("nA", [2, 6, 15, 18])
 def test_policy_act_log_softmax_gumbel_and_greedy(nA):
