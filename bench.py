@@ -232,6 +232,9 @@ def describe_call(fn, a):
     if fn == "ppo_gemm_f32":
         M, N, K = a[12:15]
         return f"gemm {M}x{N}x{K}", 2.0 * M * N * K, None
+    if fn == "ppo_dense_heads_forward_f32":  # (x, relu_x, W, b, Wh, bh, relu_h, h, heads, M, K, H, NH, ws, ws_bytes)
+        M, K, H, NH = a[9:13]
+        return f"dense + heads fwd {M}x{K}x{H} (+{NH})", 2.0 * M * H * (K + NH), None
     if fn == "ppo_gather_rows":
         return "gather observation rows", None, 2.0 * a[1] * a[4]
     if fn == "ppo_adam_step_f32":

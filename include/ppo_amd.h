@@ -221,6 +221,17 @@ size_t ppo_gemm_workspace_bytes(int M, int N, int K);
 int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const float *B, int64_t b_sk, int64_t b_sn,
                  int relu_b, const float *bias, const float *mask, float *C, int64_t ldc, int M, int N, int K,
                  void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The tail of every forward pass in one call: h[M,H] = f(x)[M,K] @ W[H,K]^T + b (the encoder's dense layer, f = ReLU when
+ * relu_x), heads[M,NH] = g(h) @ Wh[NH,H]^T + bh (the fused policy / value / advantage / TVF heads, g = ReLU when relu_h).
+ * Same results, bit for bit, as the two ppo_gemm_f32 calls it stands for; when the dense product runs K-sliced (a
+ * workspace of ppo_gemm_workspace_bytes(M,H,K) is given, K >= 512, H <= 256, NH <= 16) the slice reduction and the heads
+ * are one launch.  Replaces rl/models.py:84 (dense) + :467-506 (heads) of DualHeadNet.forward.
+ */
+int ppo_dense_heads_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh, const float *bh,
+                                int relu_h, float *h, float *heads, int M, int K, int H, int NH, void *workspace,
+                                size_t workspace_bytes, void *stream);
 /* out[n] (+)= sum_m X[m*ldx + n]  (bias gradients) */
 int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *out, int accumulate, void *stream);
 

@@ -525,6 +525,72 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     }
 }
 
+// Dense layer's split-K finalize and the fused heads in one launch (the tail of every forward pass): a wave owns a
+// row m; lane l holds columns l, l + 64, ... of h[m] = sum_s partial[s][m][:] + bias (slices added in slice order, eight
+// loads per column in flight, exactly as gemm_finalize_kernel), writes them, and the row's NH head outputs follow as in
+// gemm_rows_kernel (lane-strided fma chain, xor-shuffle reduction, lane j finishes column j): bit-identical to the
+// two launches it replaces, one launch boundary and one round trip of h less.
+template <int KPL>
+__global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__restrict__ partial, int split, int M, int H,
+                                                            const float *__restrict__ bias, float *__restrict__ h,
+                                                            const float *__restrict__ Wh, const float *__restrict__ bh, int NH,
+                                                            int relu_h, float *__restrict__ heads)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (m >= M) return;
+    const __amdgpu_buffer_rsrc_t pb = buffer_of(partial), wb = buffer_of(Wh), bb = buffer_of(bias, bias != nullptr);
+    const int stride = M * H;
+    int off[KPL];  // element offset of (m, k) inside a slice, or -1
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) off[i] = lane + 64 * i < H ? m * H + lane + 64 * i : -1;
+    float hv[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) hv[i] = 0.f;
+    int s = 0;
+    for (; s + 8 <= split; s += 8) {
+        float t[KPL][8];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[i][u] = buffer_f32(pb, off[i] < 0 ? kOutside : ((s + u) * stride + off[i]) * 4);
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hv[i] += t[i][u];
+    }
+    for (; s < split; ++s)
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) hv[i] += buffer_f32(pb, off[i] < 0 ? kOutside : (s * stride + off[i]) * 4);
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        if (bias) hv[i] += buffer_f32(bb, off[i] < 0 ? kOutside : (lane + 64 * i) * 4);
+        if (off[i] >= 0) h[off[i]] = hv[i];
+    }
+    // heads: NH <= 16 columns in one pass
+    float bv[16][KPL];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int row = min(j, NH - 1) * H;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) bv[j][i] = buffer_f32(wb, off[i] < 0 ? kOutside : (row + lane + 64 * i) * 4);
+    }
+    float out = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) acc = fmaf(relu_h ? fmaxf(hv[i], 0.f) : hv[i], bv[j][i], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        out = lane == j ? acc : out;
+    }
+    if (lane < NH) {
+        if (bh) out += bh[lane];
+        heads[m * NH + lane] = out;
+    }
+}
+
 inline bool vec_ok(const float *P, int64_t s_tile, int64_t s_k, int tile_extent, int k_extent)
 {
     // float4 along the contiguous axis: the other stride and the base keep 16-byte alignment, and the extent along
@@ -543,11 +609,20 @@ extern "C" size_t ppo_gemm_workspace_bytes(int M, int N, int K)
     return (size_t)32 * M * N * sizeof(float);  // up to 32 split-K slices
 }
 
-extern "C" int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const float *B, int64_t b_sk,
-                            int64_t b_sn, int relu_b, const float *bias, const float *mask, float *C, int64_t ldc,
-                            int M, int N, int K, void *workspace, size_t workspace_bytes, void *stream)
+namespace ppo {
+namespace {
+// the fused heads that may ride on a split-K finalize (ppo_dense_heads_forward_f32)
+struct HeadsTail {
+    const float *Wh, *bh;
+    float *heads;
+    int NH, relu_h;
+    bool fused;  // out: the finalize launch produced the heads too
+};
+
+int gemm_dispatch(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const float *B, int64_t b_sk, int64_t b_sn,
+                  int relu_b, const float *bias, const float *mask, float *C, int64_t ldc, int M, int N, int K,
+                  void *workspace, size_t workspace_bytes, void *stream, HeadsTail *tail)
 {
-    using namespace ppo;
     if (M < 0 || N < 0 || K < 0) return fail(PPO_E_INVALID, "ppo_gemm_f32: negative dimension");
     if (M == 0 || N == 0) return PPO_OK;
     if (!A || !B || !C) return fail(PPO_E_INVALID, "ppo_gemm_f32: null pointer");
@@ -613,11 +688,43 @@ extern "C" int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu
     int rc = check_launch("gemm_f32_kernel");
     if (rc) return rc;
     if (split > 1) {
+        if (tail && !mask && ldc == N && N <= 256 && tail->NH <= 16 && (int64_t)split * M * N * 4 < (int64_t)kBufferBytes) {
+            hipLaunchKernelGGL((finalize_heads_kernel<4>), dim3((M + 3) / 4), dim3(256), 0, st,
+                               static_cast<const float *>(workspace), split, M, N, bias, C, tail->Wh, tail->bh, tail->NH,
+                               tail->relu_h, tail->heads);
+            tail->fused = true;
+            return check_launch("finalize_heads_kernel");
+        }
         hipLaunchKernelGGL(gemm_finalize_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st,
                            static_cast<const float *>(workspace), split, M, N, bias, mask, C, ldc);
         rc = check_launch("gemm_finalize_kernel");
     }
     return rc;
+}
+}  // namespace
+}  // namespace ppo
+
+extern "C" int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const float *B, int64_t b_sk,
+                            int64_t b_sn, int relu_b, const float *bias, const float *mask, float *C, int64_t ldc,
+                            int M, int N, int K, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return ppo::gemm_dispatch(A, a_sm, a_sk, relu_a, B, b_sk, b_sn, relu_b, bias, mask, C, ldc, M, N, K, workspace,
+                              workspace_bytes, stream, nullptr);
+}
+
+extern "C" int ppo_dense_heads_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh,
+                                           const float *bh, int relu_h, float *h, float *heads, int M, int K, int H, int NH,
+                                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace ppo;
+    if (M < 0 || K < 0 || H <= 0 || NH <= 0) return fail(PPO_E_INVALID, "ppo_dense_heads_forward_f32: bad dimension");
+    if (M == 0) return PPO_OK;
+    if (!x || !W || !Wh || !h || !heads) return fail(PPO_E_INVALID, "ppo_dense_heads_forward_f32: null pointer");
+    HeadsTail tail{Wh, bh, heads, NH, relu_h, false};
+    int rc = gemm_dispatch(x, K, 1, relu_x, W, 1, K, 0, b, nullptr, h, H, M, H, K, workspace, workspace_bytes, stream, &tail);
+    if (rc || tail.fused) return rc;
+    // the dense product ran unsplit (no workspace, short K, wide layer): the heads are their own launch
+    return gemm_dispatch(h, H, 1, relu_h, Wh, 1, H, 0, bh, nullptr, heads, NH, M, NH, H, nullptr, 0, stream, nullptr);
 }
 
 extern "C" int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *out, int accumulate, void *stream)

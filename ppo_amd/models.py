@@ -665,7 +665,18 @@ class DualHeadNet:
             cur, cur_mode = q, IN_NONE
         flat = cur.view(B, sp.flat)
         h = self._buf(f"{tag}h", (B, sp.hidden_units))
-        self._linear(flat, sp.flat, "encoder.dense", h, relu_x=1, tag=tag)
+        if self.encoder_activation_fn == "relu":
+            # dense layer + fused heads in one call (the K-slice reduction of the dense product and the heads share a
+            # launch); heads() hands the result out
+            o = self._buf(f"{tag}heads", (B, self.nh))
+            w = self.params["encoder.dense.weight"]
+            ws_bytes = self.lib.ppo_gemm_workspace_bytes(B, sp.hidden_units, sp.flat)
+            ws = self._ws("gemm_ws" + tag, ws_bytes)
+            self._call("ppo_dense_heads_forward_f32", _p(flat), 1, _p(w), _p(self.params["encoder.dense.bias"]), _p(self.w_heads),
+                       _p(self.b_heads), 1, _p(h), _p(o), B, sp.flat, sp.hidden_units, self.nh, _p(ws), ws_bytes)
+            acts["heads"] = o
+        else:
+            self._linear(flat, sp.flat, "encoder.dense", h, relu_x=1, tag=tag)
         acts["flat"], acts["h"] = flat, h
         return acts
 
@@ -673,6 +684,8 @@ class DualHeadNet:
         """[B, nh] = act(h) @ [policy | value | advantage | tvf]^T (+ bias)  (rl/models.py:467-506).
         `acts` is encode()'s dict (or, for relu nets, the pre-activation tensor h itself)."""
         if isinstance(acts, dict):
+            if "heads" in acts:  # computed with the dense layer (encode, IMPALA / relu)
+                return acts["heads"]
             h = acts.get("hact", acts["h"])
         else:
             h = acts

@@ -238,6 +238,36 @@ def test_gemm_ragged_shapes_every_operand_layout(M, N, K, layout):
                             use_ws=False), A @ B)
 
 
+@pytest.mark.parametrize("bsz", [1, 5, 128, 256, 300])
+def test_dense_heads_forward_is_bitwise_the_two_products(bsz):
+    """ppo_dense_heads_forward_f32 (K-slice reduction of the dense product + fused heads in one launch) against the
+    two ppo_gemm_f32 calls it replaces: h and the head outputs bit for bit; without a workspace it IS the two calls."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(bsz)
+    K, H, NH = 3872, 256, 13
+    x = torch.randn(bsz, K, generator=g).to(DEV)
+    W = (torch.randn(H, K, generator=g) * 0.02).to(DEV)
+    b = torch.randn(H, generator=g).to(DEV)
+    Wh = (torch.randn(NH, H, generator=g) * 0.1).to(DEV)
+    bh = torch.randn(NH, generator=g).to(DEV)
+    h_ref = gemm(x, K, 1, 1, W, 1, K, 0, b, None, bsz, H, K)
+    o_ref = gemm(h_ref, H, 1, 1, Wh, 1, H, 0, bh, None, bsz, NH, H, use_ws=False)
+    ws_bytes = lib.ppo_gemm_workspace_bytes(bsz, H, K)
+    ws = torch.empty(ws_bytes // 4, device=DEV)
+    for use_ws in (True, False):
+        h = torch.full((bsz, H), float("nan"), device=DEV)
+        o = torch.full((bsz, NH), float("nan"), device=DEV)
+        rc = lib.ppo_dense_heads_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h), _p(o), bsz, K, H, NH,
+                                             _p(ws) if use_ws else None, ws_bytes if use_ws else 0, _st())
+        _lib.check(rc, "dense_heads")
+        if use_ws:
+            assert torch.equal(h, h_ref) and torch.equal(o, o_ref)
+        else:  # unsplit dense product: other summation order than the sliced reference, same as an unsplit gemm
+            h2 = gemm(x, K, 1, 1, W, 1, K, 0, b, None, bsz, H, K, use_ws=False)
+            assert torch.equal(h, h2) and torch.equal(o, gemm(h2, H, 1, 1, Wh, 1, H, 0, bh, None, bsz, NH, H, use_ws=False))
+    assert _close(o_ref, F.relu(F.relu(x) @ W.t() + b) @ Wh.t() + bh, 1e-4)
+
+
 def test_gemm_rejects_operands_of_2_gib_and_zero_k():
     """32-bit byte offsets inside the kernels: an operand that spans 2 GiB or more is refused (PPO_E_INVALID), nothing
     is launched.  K = 0 writes the bias (an empty sum)."""
