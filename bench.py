@@ -249,7 +249,8 @@ def describe_call(fn, a):
         return "gae scan", None, float(SCAN_BYTES_PER_ELEM) * a[7] * a[8]
     short = {"ppo_conv3x3_wgrad_reduce_f32": "wgrad slab reduction", "ppo_conv3x3_pack_weights_f32": "weight pack",
              "ppo_policy_act_f32": "policy sampling", "ppo_ppo_loss_f32": "PPO loss", "ppo_colsum_f32": "column sums",
-             "ppo_moments_f64": "advantage moments", "ppo_normalize_f32": "advantage normalise"}
+             "ppo_moments_f64": "advantage moments", "ppo_normalize_f32": "advantage normalise",
+             "ppo_heads_backward_f32": "heads backward (dh, dW, db, dense db)"}
     return short.get(fn, fn), None, None
 
 

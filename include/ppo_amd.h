@@ -232,6 +232,15 @@ int ppo_gemm_f32(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const f
 int ppo_dense_heads_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh, const float *bh,
                                 int relu_h, float *h, float *heads, int M, int K, int H, int NH, void *workspace,
                                 size_t workspace_bytes, void *stream);
+
+/*
+ * Backward of the fused heads in one launch: dh[B,H] = (dheads[B,NH] @ Wh[NH,H]) * [gate > 0] (gate [B,H] nullable: the
+ * ReLU pre-activation), dWh[NH,H] = dheads^T @ f(hin) (f = ReLU when relu_in), dbh[NH] = column sums of dheads
+ * (nullable), db_next[H] = column sums of dh (nullable: the bias gradient of the layer below when dh is final).
+ * NH <= 16.  The two column sums are bit-identical to ppo_colsum_f32.  Replaces the autograd of rl/models.py:467-506.
+ */
+int ppo_heads_backward_f32(const float *dheads, const float *hin, int relu_in, const float *gate, const float *Wh, float *dh,
+                           float *dWh, float *dbh, float *db_next, int B, int H, int NH, void *stream);
 /* out[n] (+)= sum_m X[m*ldx + n]  (bias gradients) */
 int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *out, int accumulate, void *stream);
 

@@ -591,6 +591,107 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     }
 }
 
+// Backward of the fused heads in one launch (was: a 13-row product, a 13-column product and two column sums, four
+// latency-bound launches at the head of every backward pass):
+//   dh[b][k]  = (sum_j dheads[b][j] * Wh[j][k]) * [gate[b][k] > 0]      rows: one wave per sample (blocks 0 .. XB-1)
+//   dWh[j][k] = sum_b dheads[b][j] * f(hin[b][k])                        columns: 16 per workgroup, 16 batch partitions
+//   dbh[j]    = sum_b dheads[b][j];   db_next[k] = sum_b dh[b][k]        (b = part, part + 16, ...; partitions added in order:
+//                                                                         the order ppo_colsum_f32 uses, so both are bit-identical to it)
+// NH <= 16.  Range-checked buffer reads throughout (common.h).
+struct HeadsBwdArgs {
+    const float *dheads, *hin, *gate, *Wh;
+    float *dh, *dWh, *dbh, *db_next;
+    int B, H, NH, relu_in, xb;
+};
+
+__global__ __launch_bounds__(256) void heads_backward_kernel(HeadsBwdArgs a)
+{
+    __shared__ float s_red[18][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const __amdgpu_buffer_rsrc_t db = buffer_of(a.dheads), wb = buffer_of(a.Wh), hb = buffer_of(a.hin),
+                                 gb = buffer_of(a.gate, a.gate != nullptr);
+    const bool gate_off = a.gate == nullptr;
+    if ((int)blockIdx.x < a.xb) {
+        const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (b >= a.B) return;
+        const float dl = buffer_f32(db, lane < a.NH ? (b * a.NH + lane) * 4 : kOutside);  // lane j holds dheads[b][j]
+        float dj[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)  // (the builtin moves ints: bit casts, not conversions); zeros beyond NH
+            dj[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl), j));
+        for (int k = lane; k < a.H; k += 64) {
+            float w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = buffer_f32(wb, j < a.NH ? (j * a.H + k) * 4 : kOutside);
+            const float gv = buffer_f32(gb, (b * a.H + k) * 4);
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = fmaf(dj[j], w[j], acc);
+            a.dh[b * a.H + k] = (gv > 0.f || gate_off) ? acc : 0.f;
+        }
+        return;
+    }
+    const int kk = tid & 15, part = tid >> 4;
+    const int k = ((int)blockIdx.x - a.xb) * 16 + kk;
+    const bool col = k < a.H;
+    float w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = buffer_f32(wb, (col && j < a.NH) ? (j * a.H + k) * 4 : kOutside);
+    float dW[16], dbn = 0.f, dbj = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dW[j] = 0.f;
+    for (int b0 = part; b0 < a.B; b0 += 16 * 4) {  // four samples per trip: their loads are all issued first
+        float x[4], gv[4], d[4][16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + 16 * u;
+            const bool in = b < a.B;
+            x[u] = buffer_f32(hb, (in && col) ? (b * a.H + k) * 4 : kOutside);
+            gv[u] = buffer_f32(gb, (in && col) ? (b * a.H + k) * 4 : kOutside);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[u][j] = buffer_f32(db, (in && j < a.NH) ? (b * a.NH + j) * 4 : kOutside);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float act = a.relu_in ? fmaxf(x[u], 0.f) : x[u];
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                dW[j] = fmaf(d[u][j], act, dW[j]);
+                t = fmaf(d[u][j], w[j], t);
+            }
+            dbn += (gv[u] > 0.f || gate_off) ? t : 0.f;  // rows past B contribute t = 0
+            float dsel = 0.f;  // column kk of dheads (only block xb writes the sum); a select chain, not an indexed register
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dsel = j == kk ? d[u][j] : dsel;
+            dbj += dsel;
+        }
+    }
+    // partitions are combined in partition order (deterministic)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s_red[j][tid] = dW[j];
+    s_red[16][tid] = dbn;
+    s_red[17][tid] = dbj;
+    __syncthreads();
+    if (part == 0) {
+        float tot[18];
+#pragma unroll
+        for (int v = 0; v < 18; ++v) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += s_red[v][q * 16 + kk];
+            tot[v] = t;
+        }
+        if (col) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < a.NH) a.dWh[j * a.H + k] = tot[j];
+            if (a.db_next) a.db_next[k] = tot[16];
+        }
+        if ((int)blockIdx.x == a.xb && a.dbh && kk < a.NH) a.dbh[kk] = tot[17];
+    }
+}
+
 inline bool vec_ok(const float *P, int64_t s_tile, int64_t s_k, int tile_extent, int k_extent)
 {
     // float4 along the contiguous axis: the other stride and the base keep 16-byte alignment, and the extent along
@@ -725,6 +826,18 @@ extern "C" int ppo_dense_heads_forward_f32(const float *x, int relu_x, const flo
     if (rc || tail.fused) return rc;
     // the dense product ran unsplit (no workspace, short K, wide layer): the heads are their own launch
     return gemm_dispatch(h, H, 1, relu_h, Wh, 1, H, 0, bh, nullptr, heads, NH, M, NH, H, nullptr, 0, stream, nullptr);
+}
+
+extern "C" int ppo_heads_backward_f32(const float *dheads, const float *hin, int relu_in, const float *gate, const float *Wh,
+                                      float *dh, float *dWh, float *dbh, float *db_next, int B, int H, int NH, void *stream)
+{
+    using namespace ppo;
+    if (B <= 0 || H <= 0 || NH <= 0 || NH > 16) return fail(PPO_E_INVALID, "ppo_heads_backward_f32: needs B, H > 0 and 1 <= NH <= 16");
+    if (!dheads || !hin || !Wh || !dh || !dWh) return fail(PPO_E_INVALID, "ppo_heads_backward_f32: null pointer");
+    if ((int64_t)B * H * 4 + 16 > (int64_t)kBufferBytes) return fail(PPO_E_INVALID, "ppo_heads_backward_f32: B * H spans 2 GiB; split the batch");
+    HeadsBwdArgs a{dheads, hin, gate, Wh, dh, dWh, dbh, db_next, B, H, NH, relu_in, (B + 3) / 4};
+    hipLaunchKernelGGL(heads_backward_kernel, dim3(a.xb + (H + 15) / 16), dim3(256), 0, as_stream(stream), a);
+    return check_launch("heads_backward_kernel");
 }
 
 extern "C" int ppo_colsum_f32(const float *X, int M, int N, int64_t ldx, float *out, int accumulate, void *stream)

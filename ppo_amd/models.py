@@ -471,7 +471,8 @@ class DualHeadNet:
         def param_grads():
             self._call("ppo_gemm_f32", _p(dy), 1, n, 0, _p(x), k, 1, relu_x, None, None,
                        _p(self.grads[wname + ".weight"]), k, n, k, B, None, 0)
-            self._call("ppo_colsum_f32", _p(dy), B, n, n, _p(self.grads[wname + ".bias"]), acc)
+            if not (wname == "encoder.dense" and getattr(self, "_dense_bias_done", False)):  # heads backward made it
+                self._call("ppo_colsum_f32", _p(dy), B, n, n, _p(self.grads[wname + ".bias"]), acc)
 
         if side is None:
             param_grads()
@@ -757,21 +758,29 @@ class DualHeadNet:
         main = torch.cuda.current_stream()
         side = self._wgrad_side_stream() if (WGRAD_SIDE_STREAM and self.encoder_kind == "impala") else None
 
-        def head_param_grads():
-            self._call("ppo_gemm_f32", _p(dheads), 1, self.nh, 0, _p(hin), H, 1, 1 if relu else 0, None, None,
-                       _p(self.g_w_heads), H, self.nh, H, B, None, 0)
-            if self.head_bias:
-                self._call("ppo_colsum_f32", _p(dheads), B, self.nh, self.nh, _p(self.g_b_heads), 0)
-
-        if side is None:
-            head_param_grads()
-        else:
-            side.wait_stream(main)  # dheads (and the forward activations) are complete
-            with torch.cuda.stream(side):
-                head_param_grads()
         dh = self._buf("dh", (B, H))
-        self._call("ppo_gemm_f32", _p(dheads), self.nh, 1, 0, _p(self.w_heads), H, 1, 0, None, _p(h) if relu else None,
-                   _p(dh), H, B, H, self.nh, None, 0)
+        # one launch: dh, the heads' weight / bias gradients and - when dh is final (relu) - the dense layer's bias
+        # gradient, which is the column sum of dh
+        self._dense_bias_done = bool(relu and self.encoder_kind == "impala" and self.nh <= 16)
+        if self.nh <= 16:
+            self._call("ppo_heads_backward_f32", _p(dheads), _p(hin), 1 if relu else 0, _p(h) if relu else None, _p(self.w_heads),
+                       _p(dh), _p(self.g_w_heads), _p(self.g_b_heads) if self.head_bias else None,
+                       _p(self.grads["encoder.dense.bias"]) if self._dense_bias_done else None, B, H, self.nh)
+        else:
+            def head_param_grads():
+                self._call("ppo_gemm_f32", _p(dheads), 1, self.nh, 0, _p(hin), H, 1, 1 if relu else 0, None, None,
+                           _p(self.g_w_heads), H, self.nh, H, B, None, 0)
+                if self.head_bias:
+                    self._call("ppo_colsum_f32", _p(dheads), B, self.nh, self.nh, _p(self.g_b_heads), 0)
+
+            if side is None:
+                head_param_grads()
+            else:
+                side.wait_stream(main)  # dheads (and the forward activations) are complete
+                with torch.cuda.stream(side):
+                    head_param_grads()
+            self._call("ppo_gemm_f32", _p(dheads), self.nh, 1, 0, _p(self.w_heads), H, 1, 0, None, _p(h) if relu else None,
+                       _p(dh), H, B, H, self.nh, None, 0)
         if not relu:
             self._call("ppo_tanh_backward_f32", _p(dh), _p(hin), _p(dh), dh.numel())
         if self.encoder_kind == "mlp":

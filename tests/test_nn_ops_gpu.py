@@ -268,6 +268,38 @@ def test_dense_heads_forward_is_bitwise_the_two_products(bsz):
     assert _close(o_ref, F.relu(F.relu(x) @ W.t() + b) @ Wh.t() + bh, 1e-4)
 
 
+@pytest.mark.parametrize("bsz,H,NH,relu", [(256, 256, 13, 1), (7, 256, 13, 1), (300, 64, 4, 0), (129, 100, 16, 1), (1, 256, 1, 0)])
+def test_heads_backward_one_launch(bsz, H, NH, relu):
+    """ppo_heads_backward_f32: dh, dWh against the autograd formulas; dbh / db_next bit-identical to ppo_colsum_f32 of
+    dheads / of the dh it wrote."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(bsz + H)
+    dheads = torch.randn(bsz, NH, generator=g).to(DEV)
+    h = torch.randn(bsz, H, generator=g).to(DEV)
+    Wh = torch.randn(NH, H, generator=g).to(DEV)
+    dh = torch.full((bsz, H), float("nan"), device=DEV)
+    dWh = torch.full((NH, H), float("nan"), device=DEV)
+    dbh = torch.full((NH,), float("nan"), device=DEV)
+    dbn = torch.full((H,), float("nan"), device=DEV)
+    rc = lib.ppo_heads_backward_f32(_p(dheads), _p(h), relu, _p(h) if relu else None, _p(Wh), _p(dh), _p(dWh), _p(dbh), _p(dbn),
+                                    bsz, H, NH, _st())
+    _lib.check(rc, "heads_backward")
+    act = F.relu(h) if relu else h
+    want_dh = (dheads @ Wh) * ((h > 0) if relu else 1.0)
+    assert _close(dh, want_dh, 1e-5) and _close(dWh, dheads.t() @ act, 1e-5)
+    ref = torch.empty(NH, device=DEV)
+    _lib.check(lib.ppo_colsum_f32(_p(dheads), bsz, NH, NH, _p(ref), 0, _st()), "colsum")
+    assert torch.equal(dbh, ref)
+    ref = torch.empty(H, device=DEV)
+    _lib.check(lib.ppo_colsum_f32(_p(dh), bsz, H, H, _p(ref), 0, _st()), "colsum")
+    assert torch.equal(dbn, ref)
+    # nullable outputs
+    rc = lib.ppo_heads_backward_f32(_p(dheads), _p(h), relu, None, _p(Wh), _p(dh), _p(dWh), None, None, bsz, H, NH, _st())
+    _lib.check(rc, "heads_backward")
+    assert _close(dh, dheads @ Wh, 1e-5)
+    assert lib.ppo_heads_backward_f32(_p(dheads), _p(h), relu, None, _p(Wh), _p(dh), _p(dWh), None, None, bsz, H, 17, _st()) != 0
+
+
 def test_gemm_rejects_operands_of_2_gib_and_zero_k():
     """32-bit byte offsets inside the kernels: an operand that spans 2 GiB or more is refused (PPO_E_INVALID), nothing
     is launched.  K = 0 writes the bias (an empty sum)."""
