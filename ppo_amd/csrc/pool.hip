@@ -102,24 +102,29 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
 // (j+1,k), (j+1,k+1): 4 (argmax, gradient) pairs feed 4 outputs, where the row-pair form above reads 6.
 __global__ __launch_bounds__(256) void maxpool_bwd2x2_kernel(const float *__restrict__ dout,
                                                              const uint8_t *__restrict__ argmax,
-                                                             float *__restrict__ din, int H, int W, int Ho, int Wo)
+                                                             float *__restrict__ din, int H, int W, int Ho, int Wo,
+                                                             int64_t n_windows)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Ho * Wo) return;
-    const int64_t pl = blockIdx.y;
+    // one thread per pooling window, flat over (plane, j, k): a (Ho*Wo)-per-plane grid left the last workgroup of every
+    // 21x21 plane 72 % idle.  The four (argmax, gradient) pairs are read unconditionally through range-checked
+    // descriptors based at the thread's plane (common.h): a neighbour that does not exist reads gradient 0.
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_windows) return;
+    const int64_t pl = idx / (Ho * Wo);
+    const int t = (int)(idx - pl * (Ho * Wo));
     const int j = t / Wo;
     const int k = t - j * Wo;
-    const float *g = dout + pl * Ho * Wo + t;
-    const uint8_t *a = argmax + pl * Ho * Wo + t;
     const bool right = k + 1 < Wo, down = j + 1 < Ho;
-    const int t00 = a[0];
-    const float g00 = g[0];
-    const int t01 = right ? a[1] : -1;
-    const float g01 = right ? g[1] : 0.f;
-    const int t10 = down ? a[Wo] : -1;
-    const float g10 = down ? g[Wo] : 0.f;
-    const int t11 = (right && down) ? a[Wo + 1] : -1;
-    const float g11 = (right && down) ? g[Wo + 1] : 0.f;
+    const __amdgpu_buffer_rsrc_t gb = buffer_of(dout), ab = buffer_of(argmax);  // whole tensors: the host checks < 2 GiB
+    const int o00 = (int)idx, o01 = right ? o00 + 1 : -1, o10 = down ? o00 + Wo : -1, o11 = (right && down) ? o00 + Wo + 1 : -1;
+    const int t00 = __builtin_amdgcn_raw_buffer_load_b8(ab, o00, 0, 0);
+    const int t01 = __builtin_amdgcn_raw_buffer_load_b8(ab, o01 < 0 ? kOutside : o01, 0, 0);
+    const int t10 = __builtin_amdgcn_raw_buffer_load_b8(ab, o10 < 0 ? kOutside : o10, 0, 0);
+    const int t11 = __builtin_amdgcn_raw_buffer_load_b8(ab, o11 < 0 ? kOutside : o11, 0, 0);
+    const float g00 = buffer_f32(gb, o00 * 4);
+    const float g01 = buffer_f32(gb, o01 < 0 ? kOutside : o01 * 4);
+    const float g10 = buffer_f32(gb, o10 < 0 ? kOutside : o10 * 4);
+    const float g11 = buffer_f32(gb, o11 < 0 ? kOutside : o11 * 4);
     // taps are ky*3+kx; summation order per element = window order (j,k), (j,k+1), (j+1,k), (j+1,k+1), the same
     // order the row-pair kernel uses
     const float r00 = (t00 == 4 ? g00 : 0.f);
@@ -163,9 +168,9 @@ extern "C" int ppo_maxpool3x3s2_backward_f32(const float *dout, const uint8_t *a
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
     const int threads = h * ((w + 1) / 2);
     const dim3 grid((threads + 255) / 256, n * c);
-    if (w % 2 == 0 && h % 2 == 0 && aligned(din, 8))
-        hipLaunchKernelGGL(maxpool_bwd2x2_kernel, dim3((ho * wo + 255) / 256, n * c), dim3(256), 0, as_stream(stream), dout,
-                           argmax, din, h, w, ho, wo);
+    if (w % 2 == 0 && h % 2 == 0 && aligned(din, 8) && (int64_t)n * c * ho * wo * 4 + 16 < (int64_t)kBufferBytes)
+        hipLaunchKernelGGL(maxpool_bwd2x2_kernel, dim3((unsigned)(((int64_t)n * c * ho * wo + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), dout, argmax, din, h, w, ho, wo, (int64_t)n * c * ho * wo);
     else if (w % 2 == 0 && aligned(din, 8))
         hipLaunchKernelGGL(maxpool_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), dout, argmax, din, h, w, ho, wo);
     else
