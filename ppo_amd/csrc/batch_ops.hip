@@ -28,7 +28,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t *__restr
         const int64_t n16 = row_bytes >> 4;
         const uint4 *s4 = reinterpret_cast<const uint4 *>(sp);
         uint4 *d4 = reinterpret_cast<uint4 *>(dp);
-        for (int64_t i = threadIdx.x; i < n16; i += 256) d4[i] = s4[i];
+        // eight 16-byte loads in flight per thread before the first store: the rolled copy paid one HBM round trip per
+        // 4 KB of a row (a 28 KB observation row = 7 of them in a row, 9.5 us for 256 rows)
+        for (int64_t i0 = threadIdx.x; i0 < n16; i0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + 256 * u;
+                v[u] = s4[i < n16 ? i : i0];  // clamped address, unconditional load
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + 256 * u;
+                if (i < n16) d4[i] = v[u];
+            }
+        }
     } else {
         for (int64_t i = threadIdx.x; i < row_bytes; i += 256) dp[i] = sp[i];
     }

@@ -284,6 +284,11 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
         for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
             const float *bx = s_x + buf * C::LDS_BUF, *bd = s_d + buf * C::LDS_BUF;
             PPO_STAMP(t_top)
+#ifdef PPO_TUNE_STAMPS_VM  // experiment build: how much of the barrier wait is this wave's own DMA still in flight?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PPO_STAMP(t_vm)
+            PPO_STAMP_ADD(6, t_vm, t_top)
+#endif
             __syncthreads();  // this item's bands have landed (vmcnt(0)); every wave is done with the other buffer
             PPO_STAMP(t_bar)
             if (item + (int)gridDim.x < n_items)

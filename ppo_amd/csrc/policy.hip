@@ -32,7 +32,10 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter)
     return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
 }
 
-__global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict__ heads, int B, int ldo, int nA,
+// NA: the action count at compile time (0 = any): the per-action loops unroll, the row's loads are issued together and
+// the arrays stay in registers (the runtime-count form paid one L2 round trip per action and indexed a scratch array)
+template <int NA>
+__global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict__ heads, int B, int ldo, int nA_,
                                                         float temperature, const float *__restrict__ uniform,
                                                         uint64_t seed, uint64_t offset, int greedy,
                                                         float *__restrict__ log_policy, int32_t *__restrict__ actions,
@@ -41,23 +44,29 @@ __global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict_
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const int nA = NA ? NA : nA_;
+    constexpr int kUnroll = NA ? 32 : 1;  // full unroll when the count is a constant
     const float *z = heads + (size_t)b * ldo;
     if (raw_policy)
+#pragma unroll kUnroll
         for (int a = 0; a < nA; ++a) raw_policy[(size_t)b * nA + a] = z[a];
     if (values)
         for (int i = 0; i < vh; ++i) values[(size_t)b * vh + i] = z[nA + i];
-    float logits[kMaxActions];
+    float logits[NA ? NA : kMaxActions];
     float mx = -INFINITY;
-#pragma unroll 4
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) {
         logits[a] = z[a] / temperature;
         mx = fmaxf(mx, logits[a]);
     }
     float se = 0.f;
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) se += expf(logits[a] - mx);
     const float lse = mx + logf(se);
     int best = 0;
-    float best_score = -INFINITY;
+    float best_score = -INFINITY, best_lp = 0.f;
+    bool any = false;  // no score beat -inf (NaN logits): action 0, as the running-maximum form
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) {
         const float lp = logits[a] - lse;
         logits[a] = lp;
@@ -72,44 +81,54 @@ __global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict_
         if (score > best_score) {  // first maximum wins, as np.argmax / torch.argmax
             best_score = score;
             best = a;
+            best_lp = lp;
+            any = true;
         }
     }
+    if (!any) best_lp = logits[0];
     if (actions) actions[b] = best;
-    if (log_pac) log_pac[b] = logits[best];
+    if (log_pac) log_pac[b] = best_lp;
 }
 
 // statistics row per sample (reduced on demand by the host side, one D2H per iteration)
 enum { ST_LOSS_CLIP = 0, ST_ENTROPY, ST_VALUE_LOSS, ST_CLIPPED, ST_KL_APPROX, ST_KL_TRUE, ST_GAIN, ST_RATIO, ST_N };
 
+template <int NA>
 __global__ __launch_bounds__(64) void ppo_loss_kernel(
-    const float *__restrict__ heads, int B, int ldo, int nA, int vh, const int32_t *__restrict__ actions,
+    const float *__restrict__ heads, int B, int ldo, int nA_, int vh, const int32_t *__restrict__ actions,
     const float *__restrict__ old_log_pac, const float *__restrict__ old_log_policy,
     const float *__restrict__ advantages, const float *__restrict__ returns, float eps_clip, float ent_coef,
     float vf_coef, float grad_scale, float *__restrict__ dheads, float *__restrict__ stats, const int32_t *__restrict__ index)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const int nA = NA ? NA : nA_;
+    constexpr int kUnroll = NA ? 32 : 1;  // full unroll when the count is a constant
     const float *z = heads + (size_t)b * ldo;
     const int sb = index ? index[b] : b;  // row of this sample in the (un-gathered) batch arrays
-    float lp[kMaxActions];
+    const int act = actions[sb];
+    const float adv = advantages[sb];
+    float lp[NA ? NA : kMaxActions], oldp[NA ? NA : kMaxActions];
     float mx = -INFINITY;
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) {
         lp[a] = z[a];
+        oldp[a] = old_log_policy ? old_log_policy[(size_t)sb * nA + a] : 0.f;
         mx = fmaxf(mx, lp[a]);
     }
     float se = 0.f;
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) se += expf(lp[a] - mx);
     const float lse = mx + logf(se);
-    float entropy = 0.f, kl_true = 0.f;
+    float entropy = 0.f, kl_true = 0.f, logpac = 0.f;
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) {
         lp[a] -= lse;
         const float p = expf(lp[a]);
         entropy -= p * lp[a];
-        if (old_log_policy) kl_true += p * (lp[a] - old_log_policy[(size_t)sb * nA + a]);
+        if (old_log_policy) kl_true += p * (lp[a] - oldp[a]);
+        logpac = a == act ? lp[a] : logpac;
     }
-    const int act = actions[sb];
-    const float adv = advantages[sb];
-    const float logpac = lp[act];
     const float ratio = expf(logpac - old_log_pac[sb]);
     const float clipped_ratio = fminf(fmaxf(ratio, 1.f - eps_clip), 1.f + eps_clip);
     const float s1 = ratio * adv, s2 = clipped_ratio * adv;
@@ -133,6 +152,7 @@ __global__ __launch_bounds__(64) void ppo_loss_kernel(
 
     // d(-gain)/dlogit_j = -[ dclip_dratio * ratio * (1{j=act} - p_j) + ent_coef * (-p_j (logp_j + H)) ]
     const float w = dclip_dratio * ratio;
+#pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) {
         const float p = expf(lp[a]);
         const float dpg = w * ((a == act ? 1.f : 0.f) - p);
@@ -167,9 +187,23 @@ extern "C" int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_acti
     if (B == 0) return PPO_OK;
     if (!heads) return fail(PPO_E_INVALID, "ppo_policy_act_f32: null heads");
     if (!(temperature > 0.f)) return fail(PPO_E_INVALID, "ppo_policy_act_f32: temperature must be > 0 (use greedy=1 for argmax)");
-    hipLaunchKernelGGL(policy_act_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,
-                       n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac, raw_policy,
-                       values, n_value_heads);
+#define PPO_ACT_CASE(NA)                                                                                              \
+    case NA:                                                                                                          \
+        hipLaunchKernelGGL((policy_act_kernel<NA>), dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo, \
+                           n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac,      \
+                           raw_policy, values, n_value_heads);                                                        \
+        break;
+    switch (n_actions) {  // the action counts of the benchmark suites at compile time, anything else at run time
+        PPO_ACT_CASE(4)
+        PPO_ACT_CASE(6)
+        PPO_ACT_CASE(15)
+        PPO_ACT_CASE(18)
+        default:
+            hipLaunchKernelGGL((policy_act_kernel<0>), dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,
+                               n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac,
+                               raw_policy, values, n_value_heads);
+    }
+#undef PPO_ACT_CASE
     return check_launch("policy_act_kernel");
 }
 
@@ -184,8 +218,22 @@ extern "C" int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_action
     if (B == 0) return PPO_OK;
     if (!heads || !actions || !old_log_pac || !advantages || !dheads || (n_value_heads > 0 && !returns))
         return fail(PPO_E_INVALID, "ppo_ppo_loss_f32: null pointer");
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo, n_actions,
-                       n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns, eps_clip, ent_coef,
-                       vf_coef, grad_scale, dheads, stats, index);
+#define PPO_LOSS_CASE(NA)                                                                                             \
+    case NA:                                                                                                          \
+        hipLaunchKernelGGL((ppo_loss_kernel<NA>), dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,   \
+                           n_actions, n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns,      \
+                           eps_clip, ent_coef, vf_coef, grad_scale, dheads, stats, index);                           \
+        break;
+    switch (n_actions) {
+        PPO_LOSS_CASE(4)
+        PPO_LOSS_CASE(6)
+        PPO_LOSS_CASE(15)
+        PPO_LOSS_CASE(18)
+        default:
+            hipLaunchKernelGGL((ppo_loss_kernel<0>), dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,
+                               n_actions, n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns,
+                               eps_clip, ent_coef, vf_coef, grad_scale, dheads, stats, index);
+    }
+#undef PPO_LOSS_CASE
     return check_launch("ppo_loss_kernel");
 }
