@@ -51,7 +51,7 @@ __device__ unsigned long long ppo_tune_stamps[8 * 8 * 1024];  // [workgroup][wav
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                         \
     __builtin_amdgcn_sched_barrier(0);
 #define PPO_STAMP_ADD(slot, t1, t0) \
-    if (lane == 0) ppo_tune_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + slot] += (t1) - (t0);
+    if (lane == 0) ppo_tune_stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + slot] += (t1) - (t0);
 #else
 #define PPO_STAMP(var)
 #define PPO_STAMP_ADD(slot, t1, t0)
@@ -855,27 +855,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
                     const int xo = 2 * xp + o;
-                    float b = -INFINITY;
-                    int bt = 0;
-                    bool found = false;
+                    float win[3][3];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const bool row_ok = (ky == 0) ? yo > 0 : (ky == 1 ? true : 2 * yo + 1 < H);
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const bool col_ok = (kx == 0) ? xo > 0 : (kx == 1 ? true : 2 * xo + 1 < W);
-                            if (row_ok && col_ok) {
-                                const float x = v[ky][2 * o + kx];
-                                if (!found || x > b || x != x) {
-                                    b = x;
-                                    bt = ky * 3 + kx;
-                                    found = true;
-                                }
-                            }
-                        }
-                    }
-                    best[o] = b;
-                    tap[o] = bt;
+                        for (int kx = 0; kx < 3; ++kx) win[ky][kx] = v[ky][2 * o + kx];
+                    pool_window_max<H % 2 == 0, W % 2 == 0>(win, yo > 0, 2 * yo + 1 < H, xo > 0, 2 * xo + 1 < W, best[o], tap[o]);
                 }
                 const size_t oi = ((size_t)(img * COUT + co) * C::HO + yo) * C::WO + 2 * xp;
                 *reinterpret_cast<float2 *>(out + oi) = make_float2(best[0], best[1]);
@@ -892,10 +877,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
                 const int yo = yo0 + pr;
                 float best;
                 int best_tap;
-                pool_window_lds(src, W, yo > 0, 2 * yo + 1 < H, xo > 0, 2 * xo + 1 < W, best, best_tap);
+                pool_window_lds<H % 2 == 0, W % 2 == 0>(src, W, yo > 0, 2 * yo + 1 < H, xo > 0, 2 * xo + 1 < W, best, best_tap);
                 const size_t oi = ((size_t)(img * COUT + co) * C::HO + yo) * C::WO + xo;
+#ifdef PPO_TUNE_POOL_NOSTORE  // tools/conv_tune ablation build only
+                asm volatile("" ::"v"(best), "v"(best_tap), "v"(oi));
+#else
                 out[oi] = best;
                 if (argmax) argmax[oi] = (uint8_t)best_tap;
+#endif
             }
         }
         }

@@ -487,11 +487,38 @@ __device__ __forceinline__ void zero_lds(float *__restrict__ s, int tid)
     for (int i = tid; i < WORDS; i += NTHREADS) s[i] = 0.f;
 }
 
-// 3x3 max-pool window from LDS: src -> tap (0, 0), rows `stride` floats apart; r0 / r2 (c0 / c2): the window's first /
-// last row (column) lies inside the map (the middle ones always do).  Ties go to the first tap in row-major order,
-// NaN propagates (F.max_pool2d).  All nine taps are read before the first compare, valid or not - the caller
-// guarantees the addresses are inside the LDS allocation: `if (valid) v = src[..]` made every tap a branch with a
-// full LDS wait behind it, nine round trips in a row per output.
+// Running maximum over a 3x3 pooling window in row-major tap order; v[ky][kx] may hold anything where the tap lies outside
+// the map (r0 / r2: the window's first / last row is inside, c0 / c2 likewise for columns; the middle row / column
+// always is).  F.max_pool2d's rule: the first maximum wins, NaN propagates.  No "found" flag: the tap index starts at
+// the first valid tap and the value at -inf, which gives the same result - a first tap of -inf leaves (value, index)
+// as they are, anything larger or NaN replaces them.  R2 / C2 are compile-time when the map's height / width is even
+// (the window's last row / column then always exists).
+template <bool R2_ALWAYS, bool C2_ALWAYS>
+__device__ __forceinline__ void pool_window_max(const float (&v)[3][3], bool r0, bool r2, bool c0, bool c2, float &best,
+                                                int &best_tap)
+{
+    best = -INFINITY;
+    best_tap = r0 ? (c0 ? 0 : 1) : (c0 ? 3 : 4);  // the first valid tap (taps 4, 5, 7, 8 need only r2 / c2)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float x = v[ky][kx];
+            bool take = x > best || x != x;
+            if (ky == 0) take = take && r0;
+            if (ky == 2 && !R2_ALWAYS) take = take && r2;
+            if (kx == 0) take = take && c0;
+            if (kx == 2 && !C2_ALWAYS) take = take && c2;
+            best = take ? x : best;
+            best_tap = take ? ky * 3 + kx : best_tap;
+        }
+    }
+}
+
+// The same from LDS: src -> tap (0, 0), rows `stride` floats apart.  All nine taps are read before the first compare,
+// valid or not - the caller guarantees the addresses are inside the LDS allocation: `if (valid) v = src[..]` made every
+// tap a branch with a full LDS wait behind it, nine round trips in a row per output.
+template <bool R2_ALWAYS = false, bool C2_ALWAYS = false>
 __device__ __forceinline__ void pool_window_lds(const float *src, int stride, bool r0, bool r2, bool c0, bool c2, float &best,
                                                 int &best_tap)
 {
@@ -500,22 +527,7 @@ __device__ __forceinline__ void pool_window_lds(const float *src, int stride, bo
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) v[ky][kx] = src[ky * stride + kx];
-    best = -INFINITY;
-    best_tap = 0;
-    bool found = false;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const bool row_ok = ky == 0 ? r0 : (ky == 1 ? true : r2);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const bool ok = row_ok && (kx == 0 ? c0 : (kx == 1 ? true : c2));
-            const float x = v[ky][kx];
-            const bool take = ok && (!found || x > best || x != x);
-            best = take ? x : best;
-            best_tap = take ? ky * 3 + kx : best_tap;
-            found = found || ok;
-        }
-    }
+    pool_window_max<R2_ALWAYS, C2_ALWAYS>(v, r0, r2, c0, c2, best, best_tap);
 }
 
 }  // namespace ppo

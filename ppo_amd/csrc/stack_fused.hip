@@ -745,7 +745,7 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_full_kernel(StackFullA
                     const float *src = smem + B_OFF + co * SI::PLANE + SI::G + WI + (2 * yo - 1) * WI + 2 * xo - 1;
                     float best;
                     int best_tap;
-                    pool_window_lds(src, WI, yo > 0, 2 * yo + 1 < HI, xo > 0, 2 * xo + 1 < WI, best, best_tap);
+                    pool_window_lds<HI % 2 == 0, WI % 2 == 0>(src, WI, yo > 0, 2 * yo + 1 < HI, xo > 0, 2 * xo + 1 < WI, best, best_tap);
                     smem[X_OFF + co * SO::PLANE + SO::G + WO + yo * WO + xo] = best;
                     const size_t oi = out_img + ((size_t)co * HO + yo) * WO + xo;
                     if (a.pooled) a.pooled[oi] = best;
