@@ -9,7 +9,7 @@
 // fa / fb: optional ReLU on load (the encoder keeps pre-activations and applies
 // ReLU when they are consumed); epi: optional [mask_src > 0] gate (ReLU backward).
 //
-// 64x64 output tile per 256-thread workgroup, 2x2 waves of 32x32, K staged through LDS in 32-deep
+// 64x64 output tile per 512-thread workgroup, 2x4 waves of 32x16, K staged through LDS in 32-deep
 // slabs.  Each operand slab is fetched with two 16-byte loads per thread along whichever axis is
 // contiguous in memory, one slab ahead (registers hold slab s+1 while the MFMAs run on slab s).
 // Operands that are not 16-byte friendly (heads: 13 rows) take a scalar path.  Small grids are
@@ -52,7 +52,15 @@ struct GemmArgs {
 
 // One operand slab (64 tile rows x 32 k) -> registers -> LDS.  `tfast`: the tile axis (m or n) is the
 // contiguous one, else k is.  rows = extent of the tile axis, t0/k0 origin, st/sk element strides.
-constexpr int kSlabF4 = BM * BK / 4 / 256;  // float4 per thread and operand slab
+#ifndef PPO_TUNE_GEMM_WAVES
+#define PPO_TUNE_GEMM_WAVES 8
+#endif
+// 8 waves per workgroup = two per SIMD: one wave's LDS write -> barrier -> read turnaround runs under the other's MFMAs
+// (with 4 waves a slab took 1890 cycles for 1024 of MFMA work); wave tile 32 x 16 (4 waves: 32 x 32)
+constexpr int kGemmWaves = PPO_TUNE_GEMM_WAVES, kGemmThreads = kGemmWaves * 64;
+static_assert(kGemmWaves == 4 || kGemmWaves == 8, "2 x 2 waves of 32 x 32 or 2 x 4 waves of 32 x 16");
+constexpr int kWaveN = kGemmWaves == 8 ? 16 : 32, kNJ = kWaveN / 16;  // columns per wave, 16-column MFMA tiles per wave
+constexpr int kSlabF4 = BM * BK / 4 / kGemmThreads;  // float4 per thread and operand slab
 struct Slab {
     float4 v[kSlabF4];
 };
@@ -68,7 +76,7 @@ __device__ __forceinline__ void slab_load(Slab &s, __amdgpu_buffer_rsrc_t P, int
 {
 #pragma unroll
     for (int e = 0; e < kSlabF4; ++e) {
-        const int q = tid + e * 256;  // BM * BK / 4 float4 per slab
+        const int q = tid + e * kGemmThreads;  // BM * BK / 4 float4 per slab
         int tt, kk;
         if (kfast) {
             kk = (q % (BK / 4)) * 4;  // BK / 4 float4 along k
@@ -100,7 +108,7 @@ __device__ __forceinline__ void slab_store(const Slab &s, float *__restrict__ ld
 {
 #pragma unroll
     for (int e = 0; e < kSlabF4; ++e) {
-        const int q = tid + e * 256;
+        const int q = tid + e * kGemmThreads;
         float4 r = s.v[e];
         if (relu) r = make_float4(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f));
         if (kfast) {
@@ -188,7 +196,7 @@ static_assert(DEPTH % 2 == 0, "the LDS buffer of a slab is its slot's parity");
 // a_kfast / b_kfast: which axis of each operand is contiguous in memory (k, or the tile axis); vec: both operands
 // can be fetched with aligned float4 loads
 template <bool a_kfast, bool b_kfast, bool vec>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int gn)
+__global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs p, int gm, int gn)
 {
     __shared__ __align__(16) float s_a[2][TILE_WORDS];
     __shared__ __align__(16) float s_b[2][TILE_WORDS];
@@ -199,18 +207,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
     const int wave = tid >> 6;
     const int l15 = lane & 15;
     const int g = lane >> 4;
-    const int wm = (wave >> 1) * 32;
-    const int wn = (wave & 1) * 32;
+    const int wm = (wave / (BN / kWaveN)) * 32;
+    const int wn = (wave % (BN / kWaveN)) * kWaveN;
     const int m0 = t.tm * BM;
     const int n0 = t.tn * BN;
     const int kbeg = t.z * p.k_per_slice;
     const int kend = min(p.K, kbeg + p.k_per_slice);
 
-    f32x4 acc[2][2];
+    f32x4 acc[2][kNJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < kNJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // The K slice is walked in groups of DEPTH slabs, rounded up: slabs past kend read zeros through the range
     // check (no memory traffic, a few idle MFMAs), which keeps every load of the main loop unconditional - with a
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
         // step left the MFMA pipe idle for an LDS round trip in each of the 8 steps (one wave per SIMD: nobody
         // else fills the gap)
         const float *sa = s_a[d & 1], *sb = s_b[d & 1];
-        float a[BK / 4][2], b[BK / 4][2];
+        float a[BK / 4][2], b[BK / 4][kNJ];
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
 #pragma unroll
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
                 a[ks][i] = a_kfast ? sa[(wm + i * 16 + l15) * PITCH_K + ks * 4 + g]
                                    : sa[(ks * 4 + g) * PITCH_M + wm + i * 16 + l15];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < kNJ; ++j)
                 b[ks][j] = b_kfast ? sb[(wn + j * 16 + l15) * PITCH_K + ks * 4 + g]
                                    : sb[(ks * 4 + g) * PITCH_M + wn + j * 16 + l15];
         }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[ks][i], b[ks][j], acc[i][j]);
+                for (int j = 0; j < kNJ; ++j) acc[i][j] = mfma16(a[ks][i], b[ks][j], acc[i][j]);
     };
 
     PPO_GSTAMP(0);
@@ -290,13 +298,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
         static_assert(BM * PITCH_C <= 2 * TILE_WORDS, "the output tile is staged in the A operand's buffers");
         float *sc = &s_a[0][0];
         const int row0 = tid >> 4, col = (tid & 15) * 4;
-        float4 gate[4], bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int kRowsPerPass = kGemmThreads / 16, kPasses = BM / kRowsPerPass;
+        float4 gate[kPasses], bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool col_in = n0 + col < p.N;  // N is a multiple of 4 here
         if (finish && p.mask) {
             const __amdgpu_buffer_rsrc_t bufM = operand_rsrc(p.mask);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + row0 + 16 * q;
+            for (int q = 0; q < kPasses; ++q) {
+                const int m = m0 + row0 + kRowsPerPass * q;
                 const int off = (m < p.M && col_in) ? (m * (int)p.ldc + n0 + col) * 4 : kOutside;
                 gate[q] = buffer_f32x4(bufM, off);
             }
@@ -306,14 +315,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < kNJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     sc[(wm + i * 16 + g * 4 + r) * PITCH_C + wn + j * 16 + l15] = acc[i][j][r];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + 16 * q, m = m0 + row;
+        for (int q = 0; q < kPasses; ++q) {
+            const int row = row0 + kRowsPerPass * q, m = m0 + row;
             float4 v = *reinterpret_cast<const float4 *>(sc + row * PITCH_C + col);
             if (finish) {
                 v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, int gm, int g
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < kNJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm + i * 16 + g * 4 + r;
@@ -773,7 +782,7 @@ int gemm_dispatch(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const 
     const int variant = (a_sk == 1 ? 4 : 0) | (b_sk == 1 ? 2 : 0) | (vec ? 1 : 0);
 #define PPO_GEMM_CASE(v, ak, bk, vc)                                                                  \
     case v:                                                                                           \
-        hipLaunchKernelGGL((gemm_f32_kernel<ak, bk, vc>), grid, dim3(256), 0, st, p, gm, gn);         \
+        hipLaunchKernelGGL((gemm_f32_kernel<ak, bk, vc>), grid, dim3(kGemmThreads), 0, st, p, gm, gn); \
         break;
     switch (variant) {
         PPO_GEMM_CASE(0, false, false, false)
