@@ -553,6 +553,15 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     int off[KPL];  // element offset of (m, k) inside a slice, or -1
 #pragma unroll
     for (int i = 0; i < KPL; ++i) off[i] = lane + 64 * i < H ? m * H + lane + 64 * i : -1;
+    // the head weights of this lane's columns are requested first (NH <= 16 columns, one pass): they depend on nothing
+    // and arrive under the slice sums
+    float bv[16][KPL];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int row = min(j, NH - 1) * H;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) bv[j][i] = buffer_f32(wb, off[i] < 0 ? kOutside : (row + lane + 64 * i) * 4);
+    }
     float hv[KPL];
 #pragma unroll
     for (int i = 0; i < KPL; ++i) hv[i] = 0.f;
@@ -575,14 +584,6 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     for (int i = 0; i < KPL; ++i) {
         if (bias) hv[i] += buffer_f32(bb, off[i] < 0 ? kOutside : (lane + 64 * i) * 4);
         if (off[i] >= 0) h[off[i]] = hv[i];
-    }
-    // heads: NH <= 16 columns in one pass
-    float bv[16][KPL];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int row = min(j, NH - 1) * H;
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) bv[j][i] = buffer_f32(wb, off[i] < 0 ? kOutside : (row + lane + 64 * i) * 4);
     }
     float out = 0.f;
 #pragma unroll

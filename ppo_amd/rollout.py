@@ -617,7 +617,7 @@ class Runner:
         if args.advantage_clipping is not None:
             self.norm_advantage.clamp_(-args.advantage_clipping, args.advantage_clipping)
 
-    def optimizer_step(self, optimizer=None, label="policy"):
+    def optimizer_step(self, optimizer=None, label="policy", norm_out=None):
         """All-reduce (DP) + global-norm clip + Adam in the flat buffer (rl/rollout.py:1287-1321)."""
         opt = optimizer or self.policy_optimizer
         net, cfg = opt.net, opt.cfg
@@ -626,8 +626,9 @@ class Runner:
             red.finish()  # late bucket + join of the early one that left during the backward pass
         net.adam_step(lr=self._lr(cfg), beta1=cfg.adam_beta1, beta2=cfg.adam_beta2, eps=cfg.adam_epsilon,
                       max_grad_norm=args.max_grad_norm if args.grad_clip_mode == "global_norm" else 0.0,
-                      grad_div=float(self.world), grad_norm_out=self._grad_norm, state=opt.state)
-        return self._grad_norm
+                      grad_div=float(self.world), grad_norm_out=self._grad_norm if norm_out is None else norm_out,
+                      state=opt.state)
+        return self._grad_norm if norm_out is None else norm_out
 
     def _micro_batches(self, mb, force_micro_batch_size=None):
         """(micro-batch size, count) of a per-rank minibatch of mb samples (rl/rollout.py:2310-2316): the reference
@@ -695,8 +696,7 @@ class Runner:
                     acc.after_backward()
                     self._call("ppo_colsum_f32", _p(stats), micro, n_stats, n_stats, _p(stat_rows[k]), 1 if u else 0)
                 acc.finish()
-                self.optimizer_step(optimizer, label)
-                norm_rows[k:k + 1].copy_(self._grad_norm, non_blocking=True)
+                self.optimizer_step(optimizer, label, norm_out=norm_rows[k:k + 1])  # the norm lands in its row: no copy launch
                 k += 1
         self._phase_stats[label] = (stat_rows, norm_rows, mb)
 
