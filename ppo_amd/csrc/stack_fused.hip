@@ -92,6 +92,25 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailA
         hi_r[m] = (pc % W == W - 1) ? 0.f : INFINITY;
     }
 
+    // A layer's A operand (16-byte coalesced loads of the packed weights) is requested when the PREVIOUS layer's K loop
+    // ends - its registers are free from then on - so the L2 round trip runs under that layer's epilogue and the barrier:
+    // loaded at the top of its own layer, all eight waves of the one resident workgroup sat through it, ~1 us per layer.
+    float wa[NT][KS];
+    auto load_weights = [&](int layer) {
+        const float4 *pw = reinterpret_cast<const float4 *>(a.w[layer]);
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float4 v = pw[(s4 * S::NT + n0 + n) * 64 + lane];
+                wa[n][4 * s4 + 0] = v.x;
+                wa[n][4 * s4 + 1] = v.y;
+                wa[n][4 * s4 + 2] = v.z;
+                wa[n][4 * s4 + 3] = v.w;
+            }
+    };
+    load_weights(0);
+
     for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
         __syncthreads();  // the previous image's last readers of X are done
         stage_band_chunk_dma<C, H, W, S::ROWS, PLANE, G, S::WAVES>(a.in, img, 0, smem, tid);
@@ -99,19 +118,6 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailA
 
 #pragma unroll 1
         for (int layer = 0; layer < 4; ++layer) {
-            // ---- this layer's A operand and bias: 16-byte coalesced loads, in flight across the barrier below
-            float wa[NT][KS];
-            const float4 *pw = reinterpret_cast<const float4 *>(a.w[layer]);
-#pragma unroll
-            for (int s4 = 0; s4 < KS / 4; ++s4)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float4 v = pw[(s4 * S::NT + n0 + n) * 64 + lane];
-                    wa[n][4 * s4 + 0] = v.x;
-                    wa[n][4 * s4 + 1] = v.y;
-                    wa[n][4 * s4 + 2] = v.z;
-                    wa[n][4 * s4 + 3] = v.w;
-                }
             float bias_r[NT][4];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -202,6 +208,8 @@ __global__ __launch_bounds__(NW * NSPLIT * 64) void stack_tail_kernel(StackTailA
             // ---- epilogue: lane holds pixel l15 x channels g*4..g*4+3 of each tile.  Even layers write Y, odd layers
             // add the block input (X, same positions) and overwrite it: nobody else reads those positions of X
             // during an odd layer, and the next layer's readers wait at its barrier.
+            __builtin_amdgcn_sched_barrier(0);
+            load_weights((layer + 1) & 3);  // the next layer's (after the fourth: the next image's first) A operand
             float *dst = smem + (odd ? 0 : S::LDS_MAP);
             float *save = a.save[layer];
             // the block input of an odd layer is read for ALL of the lane's elements before the first of them is
