@@ -63,6 +63,11 @@ def parse():
     p.add_argument("--no-kernel-table", action="store_true", help="skip the extra iteration behind roofline_by_kernel")
     p.add_argument("--scan-only", action="store_true", help="only the gae_scan section (rocprofv3 --pmc passes of the scan)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL)")
+    p.add_argument("--wall-limit", type=float, default=1500.0,
+                   help="launcher: seconds after which still-running ranks are stopped and the run fails")
+    p.add_argument("--dist-timeout", type=float, default=180.0, help="timeout of the process group's collectives, seconds")
+    p.add_argument("--fail-rank", type=int, default=-1, help="launcher test hook: this rank exits non-zero at start-up")
+    p.add_argument("--hang-rank", type=int, default=-1, help="launcher test hook: this rank sleeps instead of joining")
     p.add_argument("--rendezvous-only", action="store_true",
                    help="start the ranks, form the process group, all-reduce one number, print who was seen; no GPU work "
                         "(the CPU test of the launcher uses it with --backend gloo)")
@@ -70,15 +75,39 @@ def parse():
 
 
 # ----------------------------------------------------------------------------- rank launcher
+def count_gpus_without_hip():
+    """GPUs this process could address, read from the KFD topology in sysfs and the *_VISIBLE_DEVICES variables: no
+    torch.cuda / HIP call, so the launcher stays a process that has never initialised the GPU BY CONSTRUCTION
+    (torch.cuda.device_count() can fall back to hipGetDeviceCount).  None = sysfs unreadable: the ranks check."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(nodes):
+        return 0
+    have = 0
+    try:
+        for d in os.listdir(nodes):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(nodes, d, "properties")) if len(ln.split()) >= 2)
+            have += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(a):
-    """`python bench.py --gpus N` with no WORLD_SIZE: start N fresh rank processes and relay rank 0's stdout.
-    Nothing here initialises the GPU (torch.cuda.device_count() does not, on this image), so the children are
-    ordinary processes of an untouched parent — never a re-exec of a process that holds the device."""
+    """`python bench.py --gpus N` with no WORLD_SIZE: start N fresh rank processes, watch ALL of them, relay rank 0's
+    stdout.  The first rank that exits non-zero (bad device, OOM, port clash, a failed collective) or the wall limit
+    ends the run: the remaining ranks are terminated (then killed), the failing rank's stderr tail is printed and
+    the exit code is non-zero — a hang in one rank's RCCL call can no longer leave the bench waiting forever.  The
+    children are ordinary children of a parent that never touches the GPU — never a re-exec of a GPU-holding process."""
+    import signal
+    import tempfile
     n = a.gpus
     if not a.rendezvous_only:
-        import torch
-        have = torch.cuda.device_count()
-        if have < n:
+        have = count_gpus_without_hip()
+        if have is not None and have < n:
             raise SystemExit(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to report a "
                              f"{n}-GPU number from fewer devices")
     import socket
@@ -87,22 +116,64 @@ def launch_ranks(a):
         port = s.getsockname()[1]
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = []
+    procs, outs, errs = [], [], []
     for r in range(n):
+        outs.append(tempfile.TemporaryFile(mode="w+"))
+        errs.append(tempfile.TemporaryFile(mode="w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
-                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=outs[r], stderr=errs[r],
+                                      start_new_session=True))  # own process group: env threads / workers die with it
+
+    def tail(f, nbytes=3000):
+        f.flush()
+        f.seek(0, os.SEEK_END)
+        f.seek(max(0, f.tell() - nbytes))
+        return f.read()
+
+    def stop_all():
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            alive = [p for p in procs if p.poll() is None]
+            if not alive:
+                return
+            for p in alive:
+                try:
+                    os.killpg(p.pid, sig)  # exactly the groups started above
+                except ProcessLookupError:
+                    pass
+            t_end = time.monotonic() + grace
+            while time.monotonic() < t_end and any(p.poll() is None for p in alive):
+                time.sleep(0.05)
+
+    deadline = time.monotonic() + a.wall_limit
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"rank(s) failed (rank, exit code): {bad}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                bad = [(r, None) for r, c in enumerate(codes) if c is None]
+                failed = f"wall limit of {a.wall_limit:.0f} s exceeded; still running: ranks {[r for r, _ in bad]}"
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+    if failed:
+        for r, _c in bad:
+            sys.stderr.write(f"---- bench.py rank {r} stderr (tail) ----\n{tail(errs[r])}\n")
+        raise SystemExit(f"bench.py: {failed}; the other ranks were stopped")
     return 0
 
 
 def init_dist(a):
+    import datetime
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,19 +181,40 @@ def init_dist(a):
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch {a.gpus} ranks "
                          f"(`python bench.py --gpus {a.gpus}` does it itself)")
+    if a.fail_rank == rank:  # test hook of the launcher: this rank dies before the rendezvous
+        raise SystemExit(f"bench.py: rank {rank} told to fail (--fail-rank)")
+    if a.hang_rank == rank:
+        time.sleep(3600)
+    timeout = datetime.timedelta(seconds=a.dist_timeout)
     if a.rendezvous_only:
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.distributed.init_process_group(a.backend, rank=rank, world_size=world)
+            torch.distributed.init_process_group(a.backend, rank=rank, world_size=world, timeout=timeout)
         return world, rank, local
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK {local} but this node exposes "
+                         f"{torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {"device_id": torch.device("cuda", local)} if a.backend == "nccl" else {}
-        torch.distributed.init_process_group(a.backend, rank=rank, world_size=world, **kw)
+        torch.distributed.init_process_group(a.backend, rank=rank, world_size=world, timeout=timeout, **kw)
+        # first collective of the run, before any timed work: 4 bytes through the data-path backend (RCCL), then a
+        # digest comparison; a rank that cannot reach its peers fails HERE, inside `timeout`, with a message
+        from ppo_amd import parallel
+        t = torch.ones(1, dtype=torch.float32, device="cuda")
+        torch.distributed.all_reduce(t)
+        torch.cuda.synchronize()
+        seen = int(t.item())
+        parallel.assert_identical_across_ranks([t], "the rendezvous all-reduce result")
+        if seen != world:
+            raise SystemExit(f"bench.py: rendezvous all-reduce saw {seen} ranks, expected {world}")
+        if rank == 0:
+            print(f"bench.py: {seen} ranks seen over {torch.distributed.get_backend()} before any timed work",
+                  file=sys.stderr, flush=True)
     return world, rank, local
 
 

@@ -25,11 +25,11 @@ def to_plain(obj):
                 "data": torch.from_numpy(np.frombuffer(np.ascontiguousarray(obj).tobytes(), dtype=np.uint8).copy())}
     if isinstance(obj, np.generic):
         return {"__np__": str(obj.dtype), "v": obj.item()}
-    if isinstance(obj, tuple):
-        return {"__tuple__": [to_plain(x) for x in obj]}
+    if isinstance(obj, tuple):  # tuples survive a weights-only load as they are (Adam's `betas` keeps its type)
+        return tuple(to_plain(x) for x in obj)
     if isinstance(obj, list):
         return [to_plain(x) for x in obj]
-    if isinstance(obj, dict):
+    if isinstance(obj, dict):  # keys: str, or int (torch.optim's per-parameter state is keyed by parameter index)
         return {k: to_plain(v) for k, v in obj.items()}
     if obj is None or isinstance(obj, (bool, int, float, str)):
         return obj
@@ -48,6 +48,8 @@ def from_plain(obj):
         return {k: from_plain(v) for k, v in obj.items()}
     if isinstance(obj, list):
         return [from_plain(x) for x in obj]
+    if isinstance(obj, tuple):
+        return tuple(from_plain(x) for x in obj)
     return obj
 
 

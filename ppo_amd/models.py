@@ -1098,30 +1098,63 @@ class DualHeadNet:
                    _p(grad_norm_out))
 
     # ------------------------------------------------------------------ optimiser state (checkpoints)
-    def optimizer_state_dict(self):
-        """Adam state in torch.optim.Adam's layout idea (step + per-parameter exp_avg / exp_avg_sq),
-        keyed by parameter name (rl/rollout.py:394-453 stores optimizer.state_dict())."""
-        if self.exp_avg is None:
-            return {"step": 0, "state": {}}
-        state = {}
-        for name, (o, shape) in self._offsets.items():
-            n = int(np.prod(shape))
-            state[name] = {"exp_avg": self.exp_avg[o:o + n].view(shape).clone(),
-                           "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shape).clone()}
-        return {"step": self._adam_step, "state": state}
+    def parameter_order(self):
+        """Parameter names in the order of the reference module's `.parameters()` (= its state_dict order): the
+        integer keys of torch.optim.Adam.state_dict()['state'] index this list."""
+        return list(self.state_dict().keys())
 
-    def load_optimizer_state_dict(self, sd):
-        self._adam_step = int(sd.get("step", 0))
-        if not sd.get("state"):
-            self.exp_avg = self.exp_avg_sq = None
-            return
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        for name, st in sd["state"].items():
+    def adam_state_dict(self, exp_avg, exp_avg_sq, step, cfg=None):
+        """The layout of `torch.optim.Adam(net.parameters()).state_dict()` — what the reference stores per optimiser
+        (rl/rollout.py:412-421): {'state': {i: {'step': f32 scalar tensor, 'exp_avg', 'exp_avg_sq'}}, 'param_groups':
+        [{'lr', 'betas', 'eps', 'weight_decay', 'amsgrad', 'maximize', 'foreach', 'capturable', 'params': [0..n)}]},
+        i = index into `parameter_order()`.  torch creates a parameter's entry at the first step that sees a gradient
+        for it, so parameters whose gradient was never non-zero (the reference leaves them at grad=None) have none."""
+        names = self.parameter_order()
+        state = {}
+        if exp_avg is not None and step > 0:
+            touched = {}
+            for i, name in enumerate(names):
+                o, shape = self._offsets[name]
+                n = int(np.prod(shape))
+                touched[i] = (exp_avg_sq[o:o + n], exp_avg[o:o + n], shape)
+            flags = torch.stack([(v != 0).any() | (m != 0).any() for v, m, _ in touched.values()]).cpu().tolist()
+            for (i, (v, m, shape)), hit in zip(touched.items(), flags):
+                if hit:
+                    state[i] = {"step": torch.tensor(float(step), dtype=torch.float32),
+                                "exp_avg": m.view(shape).clone(), "exp_avg_sq": v.view(shape).clone()}
+        group = {"lr": float(cfg.lr) if cfg is not None else 0.0,
+                 "betas": (float(cfg.adam_beta1), float(cfg.adam_beta2)) if cfg is not None else (0.9, 0.999),
+                 "eps": float(cfg.adam_epsilon) if cfg is not None else 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def read_adam_state_dict(self, sd):
+        """(exp_avg, exp_avg_sq, step) flat buffers from a torch.optim.Adam-layout dict (see adam_state_dict) or from
+        the two layouts earlier versions of this package wrote (name-keyed per-parameter moments; whole flat buffers).
+        (None, None, 0) when the optimiser had not stepped."""
+        if "flat" in sd:  # round <= 2: separate flat state of the distil optimiser
+            return (sd["flat"]["exp_avg"].to(self.device).clone(), sd["flat"]["exp_avg_sq"].to(self.device).clone(),
+                    int(sd["step"]))
+        state = sd.get("state") or {}
+        if not state:
+            return None, None, int(sd.get("step", 0)) if not isinstance(sd.get("step"), torch.Tensor) else 0
+        names = self.parameter_order()
+        m, v, step = torch.zeros_like(self.flat), torch.zeros_like(self.flat), int(sd.get("step", 0) or 0)
+        for key, st in state.items():
+            name = names[int(key)] if not isinstance(key, str) or key.isdigit() else key
             o, shape = self._offsets[name]
             n = int(np.prod(shape))
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            m[o:o + n].copy_(torch.as_tensor(st["exp_avg"]).reshape(-1))
+            v[o:o + n].copy_(torch.as_tensor(st["exp_avg_sq"]).reshape(-1))
+            if "step" in st:
+                step = max(step, int(float(st["step"])))
+        return m, v, step
+
+    def optimizer_state_dict(self, cfg=None):
+        return self.adam_state_dict(self.exp_avg, self.exp_avg_sq, self._adam_step, cfg)
+
+    def load_optimizer_state_dict(self, sd):
+        self.exp_avg, self.exp_avg_sq, self._adam_step = self.read_adam_state_dict(sd)
 
 
 class TVFModel:

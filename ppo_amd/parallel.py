@@ -128,6 +128,14 @@ class GradReducer:
             marks[1].record(main)
             self._marks.append(marks)
 
+    def abandon(self):
+        """A minibatch that ends WITHOUT an optimiser step (a hook stopped the epoch): the early bucket's all-reduce
+        may still be in flight on the communication stream, and the next backward pass would overwrite grad[split:]
+        under it.  Make the current stream wait for it and forget it; the gradient itself is discarded."""
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
+
     def exposed_ms(self):
         """Mean time the compute stream spent between 'backward queued' and 'gradients reduced', per optimiser
         step since the last call (synchronises on the last event).  None when nothing was measured."""

@@ -52,21 +52,16 @@ class Optimizer:
         self.net.grad.zero_()
 
     def state_dict(self):
+        """`torch.optim.Adam.state_dict()` layout, as the reference checkpoints it (rl/rollout.py:412-421)."""
         if self.state is None:
-            return self.net.optimizer_state_dict()
-        if self.state.exp_avg is None:
-            return {"step": 0, "state": {}}
-        return {"step": self.state.step, "flat": {"exp_avg": self.state.exp_avg.clone(),
-                                                  "exp_avg_sq": self.state.exp_avg_sq.clone()}, "state": {}}
+            return self.net.optimizer_state_dict(self.cfg)
+        return self.net.adam_state_dict(self.state.exp_avg, self.state.exp_avg_sq, self.state.step, self.cfg)
 
     def load_state_dict(self, sd):
         if self.state is None:
             self.net.load_optimizer_state_dict(sd)
-        elif "flat" in sd:
-            self.state.ensure(self.net.flat)
-            self.state.step = int(sd["step"])
-            self.state.exp_avg.copy_(sd["flat"]["exp_avg"])
-            self.state.exp_avg_sq.copy_(sd["flat"]["exp_avg_sq"])
+        else:
+            self.state.exp_avg, self.state.exp_avg_sq, self.state.step = self.net.read_adam_state_dict(sd)
 
 
 class Runner:
@@ -144,6 +139,10 @@ class Runner:
         self._mean_std = torch.zeros(2, dtype=torch.float32, device=dev)
         self._grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sample_calls = 0
+        # base seed of the counter-based device generators (action sampling, horizon dropout): --seed when given,
+        # otherwise one draw from the run's host RNG (the reference's unseeded default gives a different stream per
+        # run, rl/config.py:749); saved in checkpoints so that a resumed run continues the same streams
+        self._device_seed = int(args.seed) if args.seed >= 0 else int(np.random.randint(1, 2**31 - 1))
         self._graphs = {}
         self._step_events = []
         self._phase_stats = {}
@@ -339,7 +338,7 @@ class Runner:
             hp, hv = self._forward_heads(self.all_obs[t, lo:hi], tag)
         A, nA = self.A, self.n_actions
         final = t >= self.N
-        seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + self.rank
+        seed = self._device_seed * 1000003 + self.rank
         counter = ((self._sample_calls + t) * A + lo) * nA
         first = t * A + lo  # first (t, env) element of this group's rows: pointer arithmetic, no tensor slicing
 
@@ -662,7 +661,11 @@ class Runner:
         def finish(self):
             if self.count > 1:
                 self.net.grad.copy_(self.acc)
-                self.net.grad_ready_hook = self.hook
+            self.restore_hook()
+
+        def restore_hook(self):
+            """Also the exit path of a failed step: the parked hook must come back whatever happened."""
+            self.net.grad_ready_hook = self.hook
 
     def _run_epochs(self, label, optimizer, epochs, mini_batch_size, step_fn, n_stats):
         """Permutation minibatching over the rollout (rl/rollout.py:2257-2407): per epoch one host shuffle
@@ -689,13 +692,16 @@ class Runner:
             order_dev = torch.from_numpy(ordering).to(self.device, non_blocking=True)
             for j in range(n_mb):
                 acc = self._Accumulator(self, net, n_micro)
-                for u in range(n_micro):
-                    idx = order_dev[j * mb + u * micro:j * mb + (u + 1) * micro]
-                    self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), micro, _p(mb_obs))
-                    stats = step_fn(mb_obs, idx, 1.0 / n_micro)
-                    acc.after_backward()
-                    self._call("ppo_colsum_f32", _p(stats), micro, n_stats, n_stats, _p(stat_rows[k]), 1 if u else 0)
-                acc.finish()
+                try:
+                    for u in range(n_micro):
+                        idx = order_dev[j * mb + u * micro:j * mb + (u + 1) * micro]
+                        self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), micro, _p(mb_obs))
+                        stats = step_fn(mb_obs, idx, 1.0 / n_micro)
+                        acc.after_backward()
+                        self._call("ppo_colsum_f32", _p(stats), micro, n_stats, n_stats, _p(stat_rows[k]), 1 if u else 0)
+                    acc.finish()
+                finally:
+                    acc.restore_hook()
                 self.optimizer_step(optimizer, label, norm_out=norm_rows[k:k + 1])  # the norm lands in its row: no copy launch
                 k += 1
         self._phase_stats[label] = (stat_rows, norm_rows, mb)
@@ -739,7 +745,7 @@ class Runner:
         net.zero_untouched_grads()
 
         keep = 1.0 - args.tvf.horizon_dropout if self.tvf is not None else 1.0
-        seed = (int(args.seed) if args.seed >= 0 else 0) * 1000003 + 7919 * (self.rank + 1)
+        seed = self._device_seed * 1000003 + 7919 * (self.rank + 1)
 
         def step(mb_obs, idx, loss_scale):
             off = self.tvf.next_dropout_offset(mb_obs.shape[0] * self.K) if keep < 1.0 else 0
@@ -883,25 +889,38 @@ class Runner:
         for j in range(n_mb):
             optimizer.zero_grad()
             acc = self._Accumulator(self, net, n_micro)
-            for u in range(n_micro):
-                sample = ordering[counter * micro:(counter + 1) * micro]
-                counter += 1
-                if thinning < 1.0:
-                    sample = sample[:int(micro * thinning)]
-                idx = torch.from_numpy(sample).to(self.device)
-                micro_context = {"epoch": epoch, "mini_batch": j, "micro_batch": u, "is_first": j == 0,
-                                 "is_last": j == n_mb - 1}
-                micro_data = {"context": micro_context}
-                for k_, v in data.items():
-                    micro_data[k_] = v if k_.startswith("*") else v[idx].contiguous()
-                outputs.append(mini_batch_func(micro_data, loss_scale=1 / n_micro))
-                acc.after_backward()
-                if hooks is not None and "after_micro_batch" in hooks:
-                    hooks["after_micro_batch"](micro_context)
-            acc.finish()
+            try:
+                for u in range(n_micro):
+                    sample = ordering[counter * micro:(counter + 1) * micro]
+                    counter += 1
+                    if thinning < 1.0:
+                        sample = sample[:int(micro * thinning)]
+                    idx = torch.from_numpy(sample).to(self.device)
+                    micro_context = {"epoch": epoch, "mini_batch": j, "micro_batch": u, "is_first": j == 0,
+                                     "is_last": j == n_mb - 1}
+                    micro_data = {"context": micro_context}
+                    for k_, v in data.items():
+                        micro_data[k_] = v if k_.startswith("*") else v[idx].contiguous()
+                    outputs.append(mini_batch_func(micro_data, loss_scale=1 / n_micro))
+                    acc.after_backward()
+                    if hooks is not None and "after_micro_batch" in hooks:
+                        hooks["after_micro_batch"](micro_context)
+                acc.finish()
+            finally:
+                acc.restore_hook()
             context = {"mini_batches": j + 1, "outputs": outputs}
             if hooks is not None and "after_mini_batch" in hooks:
-                if hooks["after_mini_batch"](context):
+                stop = bool(hooks["after_mini_batch"](context))
+                if self.world > 1:
+                    # a stop decided from rank-local data (a KL threshold, say) must be everyone's: otherwise one rank
+                    # leaves while the others issue the late-bucket all-reduce and the collective sequences diverge
+                    flag = torch.tensor([1.0 if stop else 0.0], device=self.device)
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                    stop = bool(flag.item() > 0)
+                if stop:
+                    red = self._reducers.get(id(net))
+                    if red is not None:
+                        red.abandon()  # the early bucket already left during the backward pass: join it before leaving
                     context["did_break"] = True
                     break
             self.optimizer_step(optimizer, label)
@@ -949,9 +968,11 @@ class Runner:
         state, its reward normaliser, its host RNG (minibatch permutations) — is gathered to rank 0 and stored as one
         entry per rank.  Every rank must call this (it is a collective when world > 1)."""
         from . import checkpoint
-        local = {"np_random": np.random.get_state(), "ep_count": self.ep_count, "time": self.time.copy()}
+        local = {"np_random": np.random.get_state(), "ep_count": self.ep_count, "time": self.time.copy(),
+                 "episode_score": self.episode_score.copy(), "episode_len": self.episode_len.copy()}
         if self.tvf is not None:
             local["episode_length_buffer"] = [int(x) for x in self.tvf.episode_length_buffer]  # rl/rollout.py:399
+            local["tvf_dropout_calls"] = int(self.tvf._dropout_calls)  # a resumed run must not replay dropout masks
         if not disable_env_state and self.vec_env is not None:
             local["env_state"] = checkpoint.save_env_state(self.vec_env)
         per_rank = [local]
@@ -960,13 +981,18 @@ class Runner:
             torch.distributed.gather_object(checkpoint.to_plain(local), per_rank, dst=0)
         if self.rank != 0:
             return None
-        data = {"step": step, "ep_count": self.ep_count, "batch_counter": self.batch_counter, "world": self.world,
-                "model_state_dict": dict(self.model.state_dict()), "sample_calls": self._sample_calls,
+        # the reference's top-level keys (rl/rollout.py:396-407; tests/golden/checkpoint_golden.json is their tree) ...
+        data = {"step": step, "ep_count": self.ep_count, "batch_counter": self.batch_counter,
+                "episode_length_buffer": [int(x) for x in self.tvf.episode_length_buffer] if self.tvf is not None else [1000],
+                "model_state_dict": dict(self.model.state_dict()), "reward_scale": float(self.reward_scale) if self.vec_env is not None else 1.0,
+                "episode_score": self.episode_score.copy(),
+                # ... and this package's own: the data-parallel layout and the device generators' position
+                "world": self.world, "sample_calls": self._sample_calls, "device_seed": self._device_seed,
                 "rank_state": per_rank}
-        if not disable_optimizer:
-            data["policy_optimizer_state_dict"] = self.policy_optimizer.state_dict()
-            if self.dual:
-                data["value_optimizer_state_dict"] = self.value_optimizer.state_dict()
+        if not disable_optimizer:  # torch.optim.Adam.state_dict() layout each; the reference writes the value
+            data["policy_optimizer_state_dict"] = self.policy_optimizer.state_dict()  # optimiser's even when it is
+            data["value_optimizer_state_dict"] = self.value_optimizer.state_dict()    # the policy optimiser (single)
+            if self.distil_optimizer is not None:
                 data["distil_optimizer_state_dict"] = self.distil_optimizer.state_dict()
         if self.model.obs_norm is not None:
             data["obs_rms"] = self.model.obs_norm.state_dict()  # rl/rollout.py:438-439
@@ -989,6 +1015,7 @@ class Runner:
         self.ep_count = cp.get("ep_count", 0)
         self.batch_counter = cp.get("batch_counter", 0)
         self._sample_calls = cp.get("sample_calls", 0)
+        self._device_seed = int(cp.get("device_seed", self._device_seed))
         ranks = cp.get("rank_state") or []
         if len(ranks) == self.world:
             mine = ranks[self.rank]
@@ -997,9 +1024,14 @@ class Runner:
             self.ep_count = mine.get("ep_count", self.ep_count)
             if mine.get("time") is not None:
                 self.time = np.asarray(mine["time"], np.int32).copy()
+            for key in ("episode_score", "episode_len"):
+                if mine.get(key) is not None:
+                    getattr(self, key)[:] = mine[key]
             if self.tvf is not None and mine.get("episode_length_buffer") is not None:
                 self.tvf.episode_length_buffer.clear()
                 self.tvf.episode_length_buffer.extend(mine["episode_length_buffer"])
+            if self.tvf is not None:
+                self.tvf._dropout_calls = int(mine.get("tvf_dropout_calls", self.tvf._dropout_calls))
             if mine.get("env_state") and self.vec_env is not None:
                 checkpoint.restore_env_state(self.vec_env, mine["env_state"])
                 if hasattr(self.vec_env, "parts"):

@@ -8,6 +8,8 @@ Build container only (needs /root/reference; see ref_shim.py):  python tests/gol
 Variants (each: seeded init hashes, forward outputs, one minibatch of every phase with losses + gradients):
   mlp_gauss_tvf   mlp / tanh / dual / gaussian (3 actions) / 8 TVF heads / obs (11,) / hidden 64   [C5-shaped]
   mlp_disc        mlp / relu / dual / discrete (2 actions) / obs (4,) / hidden 64                   [C1-shaped + DNA]
+  humanoid        mlp / tanh / dual / gaussian (17 actions) / 128 TVF heads (max horizon 30000: the geometric
+                  spacing keeps the distinct ones) / obs (377,) / hidden 256      [BASELINE configs[4] at its real size]
 """
 import hashlib
 import json
@@ -150,7 +152,7 @@ def run_variant(tag, flags, input_dims, n_actions, action_dist, activation, use_
     record_grads(f"{tag}_distil", model.policy_net, m)
 
 
-VARIANTS = ("mlp_gauss_tvf", "mlp_disc")
+VARIANTS = ("mlp_gauss_tvf", "mlp_disc", "humanoid")
 
 
 def main():
@@ -169,12 +171,16 @@ def main():
     which = sys.argv[1]
     common = ["--device=cpu", "--env_reward_normalization=off", "--disable_ev=True", "--output_folder=/tmp/ref_golden_out",
               f"--agents={MB}", "--n_steps=4", "--seed=7", "--model_architecture=dual", "--model_encoder=mlp",
-              "--model_hidden_units=64", f"--policy_opt_mini_batch_size={MB}", f"--value_opt_mini_batch_size={MB}",
-              f"--distil_opt_mini_batch_size={MB}"]
+              f"--model_hidden_units={256 if which == 'humanoid' else 64}", f"--policy_opt_mini_batch_size={MB}",
+              f"--value_opt_mini_batch_size={MB}", f"--distil_opt_mini_batch_size={MB}"]
     if which == "mlp_gauss_tvf":
         run_variant(which, common + ["--env_type=mujoco", "--env_name=Humanoid", "--tvf_enabled=True",
                                      "--tvf_value_heads=8", "--tvf_max_horizon=1000"],
                     (11,), 3, "gaussian", "tanh", True, 64)
+    elif which == "humanoid":
+        run_variant(which, common + ["--env_type=mujoco", "--env_name=Humanoid", "--tvf_enabled=True",
+                                     "--tvf_value_heads=128", "--tvf_max_horizon=30000"],
+                    (377,), 17, "gaussian", "tanh", True, 256)
     else:
         run_variant(which, common + ["--env_type=atari", "--tvf_enabled=False"], (4,), 2, "discrete", "relu", False, 64)
     part = os.path.join("/tmp", f"variants_{which}.npz")

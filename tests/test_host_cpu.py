@@ -287,6 +287,23 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
 
 
+def test_bench_launcher_stops_everything_when_a_rank_dies_or_hangs():
+    """One rank exits before the rendezvous: the launcher must notice (it polls every rank, not just rank 0), stop
+    the rank still waiting in init_process_group, show the dead rank's stderr and exit non-zero well inside the
+    process group's own timeout.  A rank that never joins is ended by the wall limit the same way."""
+    import time
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--rendezvous-only", "--backend", "gloo", "--fail-rank", "1", "--dist-timeout", "120")
+    assert r.returncode != 0
+    assert "rank(s) failed" in r.stderr and "(1, 1)" in r.stderr and "told to fail" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 60, "the launcher waited for the collective timeout instead of the dead rank"
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--rendezvous-only", "--backend", "gloo", "--hang-rank", "0", "--wall-limit", "8",
+               "--dist-timeout", "120")
+    assert r.returncode != 0 and "wall limit" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 60
+
+
 def test_u8_unit_recipe_is_the_exact_quotient():
     """csrc/conv_stage.h u8_unit: q = x * fl(1/255); q = fma(fma(q, -255, x), fl(1/255), q) equals fl(x / 255) for every
     uint8 x.  float32 FMAs are emulated exactly in float64 (products and sums of these magnitudes are exact there)."""

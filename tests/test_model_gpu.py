@@ -80,6 +80,43 @@ def test_forward_matches_reference(gold_shapes):
     assert g["fwd_logit_margin"].min() > 1e-5  # fixture has no near-tie that reassociation could flip
 
 
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4"])
+def test_greedy_actions_index_exact_on_256_observations(tag, golden_dir):
+    """The north star's gate "greedy actions bit-exact on fixed seeds", on 256 observations per network shape and with
+    two policy heads (tests/golden/make_greedy_golden.py): the freshly initialised one, and a stored wide head whose
+    logits are centred over the batch so that every action is some observation's greedy choice.  Index-exact on every
+    row whose reference top-1 / top-2 margin exceeds 1e-5; the rows at or below it are counted and must be few."""
+    import hashlib
+    z = np.load(os.path.join(golden_dir, "greedy_golden.npz"))
+    jm = json.load(open(os.path.join(golden_dir, "greedy_golden.json")))
+    _g, meta = _load(golden_dir, tag)
+    dims = tuple(jm["shapes"][tag][0])
+    x = np.random.default_rng(jm["obs_seed"][tag]).integers(0, 256, size=(jm["batch"], *dims), dtype=np.uint8)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == jm["obs_sha256"][tag], "this NumPy draws different observations"
+    net = make_net(meta)
+    xd = torch.from_numpy(x).cuda()
+    checked = 0
+    for prefix in ("", "wide_"):
+        if prefix:
+            net.params["policy_head.weight"].copy_(torch.from_numpy(z[f"{tag}_wide_head_weight"]).cuda())
+            net.params["policy_head.bias"].copy_(torch.from_numpy(z[f"{tag}_wide_head_bias"]).cuda())
+        out0 = net.forward(xd, policy_temperature=0.0)
+        out1 = net.forward(xd, policy_temperature=1.0)
+        torch.cuda.synchronize()
+        want, margin = z[f"{tag}_{prefix}greedy_actions"], z[f"{tag}_{prefix}logit_margin"]
+        assert rel_err(out1["raw_policy"].cpu().numpy(), z[f"{tag}_{prefix}raw_policy"]) < 1e-4
+        got = out0["argmax_policy"].argmax(1).cpu().numpy()
+        assert np.array_equal(got, out1["raw_policy"].argmax(1).cpu().numpy())
+        decided = margin > 1e-5
+        assert int((~decided).sum()) <= 2, f"{int((~decided).sum())} fixture rows are near-ties"
+        bad = np.flatnonzero(decided & (got != want))
+        assert bad.size == 0, (prefix, bad.tolist(), margin[bad].tolist())
+        checked += int(decided.sum())
+        if prefix:
+            assert len(np.unique(want)) == meta["n_actions"], "the wide head must exercise every action"
+    assert checked >= 2 * jm["batch"] - 4
+
+
 def test_forward_is_batch_size_independent(gold):
     g, meta = gold
     net = make_net(meta)

@@ -43,6 +43,34 @@ def rel(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
 
 
+def test_accumulated_gradient_equals_the_one_pass_gradient_before_adam():
+    """The quantity itself, before any optimiser amplifies it: the gradient buffer after the 4 micro-batch passes of a
+    minibatch (summed by ppo_accumulate_f32) against the gradient of the same 128 samples in one pass — float32
+    round-off of a different summation order, nothing else.  An `after_mini_batch` hook that stops the epoch leaves the
+    buffer as the optimiser step would have seen it."""
+    grads = []
+    for micro in (None, 32):
+        r = make()
+        np.random.seed(77)
+        ctx = r.train_batch(batch_of(r), r.train_policy_minibatch, 128, r.policy_optimizer, "policy", epoch=0,
+                            force_micro_batch_size=micro, hooks={"after_mini_batch": lambda c: True})
+        assert ctx["did_break"] and len(ctx["outputs"]) == (1 if micro is None else 4) and r.net._adam_step == 0
+        torch.cuda.synchronize()
+        grads.append({n: g.clone() for n, g in r.net.grads.items()})
+        flat = r.net.grad.clone()
+        grads.append(flat)
+    (one, one_flat), (acc, acc_flat) = (grads[0], grads[1]), (grads[2], grads[3])
+    gmax = float(one_flat.abs().max())
+    assert gmax > 1e-3
+    assert float((acc_flat - one_flat).abs().max()) <= 2e-6 * gmax, "accumulated gradient is not the one-pass gradient"
+    for n in one:
+        tmax = float(one[n].abs().max())
+        if tmax > 0:
+            assert float((acc[n] - one[n]).abs().max()) <= 1e-5 * tmax, n
+        else:
+            assert float(acc[n].abs().max()) == 0.0, n
+
+
 def test_train_batch_micro_batches_accumulate_to_the_same_update():
     ref = make()
     np.random.seed(77)
@@ -64,9 +92,16 @@ def test_train_batch_micro_batches_accumulate_to_the_same_update():
     torch.cuda.synchronize()
     # Adam's first steps move a weight by ~lr * g / (|g| + eps): where |g| ~ eps = 1e-5 a rounding difference of the
     # gradient is amplified to a fraction of a learning-rate step; everywhere else the updates coincide
+    # gradient (see the test above: equal to float32 round-off, ~1e-8 absolute) is amplified to a fraction of a
+    # learning-rate step.  So: a loose bar on those weights, a tight one wherever the gradient is well above eps
+    # (|exp_avg| after two steps ~ 0.19 |g|), and the moments themselves to round-off.
+    lr = 2.5e-4
     d = (split.net.flat - ref.net.flat).abs()
-    assert float(d.max()) < 0.25 * 2 * 2.5e-4 and float(d.median()) < 1e-3 * 2.5e-4
-    assert rel(split.net.exp_avg, ref.net.exp_avg) < 1e-4, "accumulated gradient differs from the one-pass gradient"
+    assert float(d.max()) < 0.25 * 2 * lr and float(d.median()) < 1e-3 * lr
+    clear = ref.net.exp_avg.abs() > 2e-4  # |g| >~ 1e-3 = 100 eps
+    assert int(clear.sum()) > 1000
+    assert float(d[clear].max()) < 1e-3 * lr, "a weight with a clear gradient moved differently"
+    assert rel(split.net.exp_avg, ref.net.exp_avg) < 1e-5, "accumulated gradient differs from the one-pass gradient"
 
     # a hook that stops the epoch: no optimiser step for that minibatch
     stop = make()

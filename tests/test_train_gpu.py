@@ -103,3 +103,74 @@ def test_restored_runner_continues_bit_identically(tmp_path):
     assert torch.equal(a.net.flat, b.net.flat), "parameters diverged after resume (minibatch permutation RNG?)"
     assert torch.equal(a.net.exp_avg, b.net.exp_avg) and torch.equal(a.net.exp_avg_sq, b.net.exp_avg_sq)
     assert a.step == b.step and a.net._adam_step == b.net._adam_step and a.ep_count == b.ep_count
+
+
+# ---------------------------------------------------------------- checkpoint structure vs the reference's
+def _tree(v):
+    """The describe() of tests/golden/make_checkpoint_golden.py, applied to what checkpoint.load returns."""
+    if isinstance(v, torch.Tensor):
+        return {"__tensor__": str(v.dtype).replace("torch.", ""), "shape": list(v.shape)}
+    if isinstance(v, np.ndarray):
+        return {"__ndarray__": str(v.dtype), "shape": list(v.shape)}
+    if isinstance(v, dict):
+        return {"__dict__": {str(k): _tree(x) for k, x in v.items()}, "key_type": sorted({type(k).__name__ for k in v})}
+    if isinstance(v, (list, tuple)):
+        kinds = [_tree(x) for x in v]
+        same = all(k == kinds[0] for k in kinds) if kinds else True
+        return {"__seq__": type(v).__name__, "len": len(v), "items": kinds[:1] if same else kinds}
+    return {"__scalar__": type(v).__name__}
+
+
+# reference keys this package does not write, and why: `logs` is the pickled Logger object and `env_state` pickles gym
+# wrappers (here: plain per-rank `rank_state[*]['env_state']`); `stats` / `vars` / `discounted_episode_score` are
+# logging accumulators of features outside the hot path (reward clipping, crash counting, SNS); the fixture itself was
+# taken with logs and env state disabled.
+NOT_WRITTEN = {"stats", "vars", "discounted_episode_score"}
+CORE_GROUP_KEYS = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "foreach", "capturable", "params")
+
+
+def test_checkpoint_key_tree_matches_the_reference(tmp_path, golden_dir):
+    """Same top-level keys, same model_state_dict names / shapes, and every optimiser entry in
+    torch.optim.Adam.state_dict() layout with state under the same parameter indices, tensor for tensor, as the
+    reference's Runner.save_checkpoint produced (rl/rollout.py:394-453; tests/golden/checkpoint_golden.json).  A real
+    torch.optim.Adam over parameters of these shapes must accept the optimiser entry."""
+    import json
+    from ppo_amd import checkpoint
+    want = json.load(open(os.path.join(golden_dir, "checkpoint_golden.json")))["impala_single"]
+    ref = want["tree"]["__dict__"]
+    r = make_runner(3, str(tmp_path))
+    iteration(r)
+    path = r.save_checkpoint(str(tmp_path / "checkpoint-000M-params.pt"), r.step)
+    cp = checkpoint.load(path)
+    got = _tree(cp)["__dict__"]
+    missing = set(ref) - set(got)
+    assert missing == NOT_WRITTEN, missing
+    # entries that are the same kind of thing on both sides (per-env arrays differ in the env count only)
+    for k in ("step", "ep_count", "batch_counter", "reward_scale"):
+        assert got[k] == ref[k], k
+    assert got["episode_score"]["__ndarray__"] == ref["episode_score"]["__ndarray__"]
+    assert got["model_state_dict"] == ref["model_state_dict"]
+    assert list(cp["model_state_dict"])[:39] == ["policy_net." + n for n in want["policy_param_names"]]
+    for k in ("policy_optimizer_state_dict", "value_optimizer_state_dict"):
+        g, w = got[k]["__dict__"], ref[k]["__dict__"]
+        assert set(g) == {"state", "param_groups"}
+        gg, wg = g["param_groups"]["items"][0]["__dict__"], w["param_groups"]["items"][0]["__dict__"]
+        for key in CORE_GROUP_KEYS:
+            assert gg[key] == wg[key], (k, key)
+        ours = cp[k]["param_groups"][0]
+        for key in ("lr", "eps", "weight_decay", "amsgrad"):
+            assert ours[key] == want["param_groups"][k][key]
+        assert list(ours["betas"]) == want["param_groups"][k]["betas"] and len(ours["params"]) == want["param_groups"][k]["n_params"]
+    # the policy optimiser stepped on both sides: state under the same indices with the same tensors
+    assert got["policy_optimizer_state_dict"]["__dict__"]["state"] == ref["policy_optimizer_state_dict"]["__dict__"]["state"]
+    assert sorted(cp["policy_optimizer_state_dict"]["state"]) == want["param_groups"]["policy_optimizer_state_dict"]["state_indices"]
+    # ... and torch's own Adam takes it
+    shapes = [tuple(t.shape) for t in list(cp["model_state_dict"].values())[:39]]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    adam = torch.optim.Adam(params, lr=1.0)
+    adam.load_state_dict(cp["policy_optimizer_state_dict"])
+    assert adam.param_groups[0]["lr"] == 2.5e-4 and adam.param_groups[0]["eps"] == 1e-5
+    o, shape = r.net._offsets["encoder.dense.weight"]
+    idx = want["policy_param_names"].index("encoder.dense.weight")
+    assert torch.equal(adam.state[params[idx]]["exp_avg"], r.net.exp_avg[o:o + int(np.prod(shape))].view(shape).cpu())
+    assert float(adam.state[params[idx]]["step"]) == r.net._adam_step

@@ -62,7 +62,7 @@ def check_grads(net, tag, phase, m, tol=2e-5):
     assert seen >= 6
 
 
-@pytest.mark.parametrize("tag", ["mlp_gauss_tvf", "mlp_disc"])
+@pytest.mark.parametrize("tag", ["mlp_gauss_tvf", "mlp_disc", "humanoid"])
 def test_state_dict_keys_and_forward_routing(tag):
     model, m, tvf = build(tag)
     assert list(model.state_dict().keys()) == m["state_dict_keys"]
@@ -78,8 +78,10 @@ def test_state_dict_keys_and_forward_routing(tag):
         close(sub, GOLD[f"{tag}_fwd_value_tvf_value"][:, [0, 3]], 2e-6, "required_tvf_heads")
 
 
-def test_gaussian_policy_value_and_distil_minibatches():
-    tag = "mlp_gauss_tvf"
+@pytest.mark.parametrize("tag", ["mlp_gauss_tvf", "humanoid"])
+def test_gaussian_policy_value_and_distil_minibatches(tag):
+    """`humanoid` is BASELINE configs[4] at its real size: 377 float observations, 256 tanh units, 17 gaussian
+    actions, 128 TVF heads out to horizon 30 000."""
     model, m, _ = build(tag)
     x = cuda(GOLD[f"{tag}_x"])
     pol, val = model.policy_net, model.value_net

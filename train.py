@@ -57,18 +57,20 @@ def resolve_log_folder(rank=0, world=1):
     every rank uses its answer."""
     import uuid
     if args.log_folder is None:
-        guid = None
+        guid, error = None, None
         if rank == 0:
             if args.restore in ("always", "auto"):
                 guid = get_previous_experiment_guid(os.path.join(args.output_folder, args.experiment_name), args.run_name)
                 if guid is None and args.restore == "always":
-                    raise SystemExit(f"Could not restore experiment {args.experiment_name}:{args.run_name}. "
-                                     "Previous run not found.")
+                    error = (f"Could not restore experiment {args.experiment_name}:{args.run_name}. "
+                             "Previous run not found.")
             guid = guid or uuid.uuid4().hex[-8:]
-        if world > 1:
-            box = [guid]
+        if world > 1:  # the error travels with the answer: every rank leaves together, none waits in the broadcast
+            box = [guid, error]
             torch.distributed.broadcast_object_list(box, src=0)
-            guid = box[0]
+            guid, error = box
+        if error:
+            raise SystemExit(error)
         args.log_folder = "{} [{}]".format(os.path.join(args.output_folder, args.experiment_name, args.run_name), guid)
     if rank == 0:
         os.makedirs(args.log_folder, exist_ok=True)
