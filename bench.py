@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--no-scan", action="store_true")
     p.add_argument("--no-kernel-table", action="store_true", help="skip the extra iteration behind roofline_by_kernel")
     p.add_argument("--scan-only", action="store_true", help="only the gae_scan section (rocprofv3 --pmc passes of the scan)")
+    p.add_argument("--tvf-only", action="store_true", help="only the tvf_returns section (timing / rocprofv3 passes)")
+    p.add_argument("--tvf-heads", type=int, default=108, help="K = V of the tvf_returns section")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL)")
     p.add_argument("--wall-limit", type=float, default=1500.0,
                    help="launcher: seconds after which still-running ranks are stopped and the run fails")
@@ -455,6 +457,57 @@ def bench_scan(lib, N, A_big, A_cfg):
     return out
 
 
+# ----------------------------------------------------------------------------- TVF returns section
+def bench_tvf(K_heads=108, N=256, A=256, reps=20):
+    """ppo_tvf_returns_f32 (rl/returns_truncated.py:623-693) at SURVEY.md §8(d)'s size: N = A = 256, K = V = 108
+    geometric heads out to 30 000, 8 exponential n-step samples per head (`advanced` mode, n_step 20: the
+    reference's TVF defaults).  Algorithmic bytes = 4 (N+1) A V read + 4 N A K written; HIP events on the launch
+    stream around each launch; checked bit for bit against the NumPy oracle on a sample of env columns."""
+    import numpy as np
+    import torch
+    from ppo_amd import returns_truncated as RT
+    from ppo_amd.tvf import get_value_head_horizons
+    dev = torch.device("cuda")
+    hz = get_value_head_horizons(K_heads, 30000)
+    K = V = len(hz)
+    rng = np.random.default_rng(1)
+    rewards = rng.normal(size=(N, A)).astype(np.float32)
+    dones = rng.random((N, A)) < 0.01
+    vs = rng.normal(size=(N + 1, A, V)).astype(np.float32)
+    vs[:, :, 0] = 0
+    np.random.seed(3)
+    samples = RT._draw_samples("exponential", "advanced", N, np.asarray(hz), 20, 8, None)
+    plan = RT.SampledReturnPlan(N, A, hz, hz, samples, False, dev)
+    r, d, v = (torch.from_numpy(x).to(dev) for x in (rewards, dones.view(np.uint8), vs))
+    out = torch.empty((N, A, K), dtype=torch.float32, device=dev)
+    for _ in range(3):
+        plan.launch(0.999, r, d, v, out)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for k in range(reps):
+        plan.launch(0.999, r, d, v, out)
+        ev[k + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))
+    ms = sum(per) / reps
+    nbytes = 4 * (N + 1) * A * V + 4 * N * A * K
+    from oracle import returns_truncated as T
+    cols = np.arange(0, A, max(1, A // 8))[:8]
+    ref = T.sampled_returns(0.999, rewards[:, cols], dones[:, cols], hz, hz, vs[:, cols], samples)
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    return {"N": N, "A": A, "K": K, "V": V, "samples_per_head": int(samples.shape[1]), "distinct_n": plan.ND,
+            "max_n": plan.max_n, "algorithmic_bytes": nbytes, "avg_kernel_us": round(ms * 1e3, 2),
+            "min_kernel_us": round(per[0] * 1e3, 2), "max_kernel_us": round(per[-1] * 1e3, 2), "launches_timed": reps,
+            "achieved_GBps": round(gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+            "terms": N * A * K * int(samples.shape[1]),
+            "kernel": "tvf_column_kernel (one workgroup per env column, value samples resident in LDS)"
+                      if os.environ.get("PPO_AMD_TVF_COLUMN", "1") != "0" else "tvf_prefix_kernel + tvf_gather_kernel",
+            "bit_exact_vs_oracle": bool(np.array_equal(out[:, cols].cpu().numpy(), ref)),
+            "bound": "VALU issue (about 15 wave instructions per (t, a, k, c) term: the float64 blend of NumPy's "
+                     "promotion rules), not HBM; see DESIGN.md §4"}
+
+
 # ----------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(N, A, epochs, mb):
     """The PPO iteration on the host through plain torch CPU ops (oracle/model_torch.py), bounded: one rollout
@@ -535,6 +588,9 @@ def main():
     N, A = a.n_steps, a.agents
     if a.scan_only:
         print(json.dumps({"gae_scan": bench_scan(lib, N, a.scan_envs, A)}), flush=True)
+        return 0
+    if a.tvf_only:
+        print(json.dumps({"tvf_returns": bench_tvf(a.tvf_heads)}), flush=True)
         return 0
     mb = 256
     args.setup([f"--agents={A}", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala",
@@ -691,6 +747,7 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_scan:
             out["gae_scan"] = bench_scan(lib, N, a.scan_envs, A)
+            out["tvf_returns"] = bench_tvf(a.tvf_heads)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, A, args.policy_opt.epochs, mb)
         print(json.dumps(out), flush=True)

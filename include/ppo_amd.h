@@ -384,10 +384,11 @@ int ppo_accumulate_f32(float *dst, const float *src, int64_t n, void *stream);
  *   main_plan [K,C,3] i32 + main_w [K,C,2] f64      interpolation at horizon h_k-n: (mode, i0, i1), (w0, w1);
  *   tail_plan [K,N+1,3] i32 + tail_w [K,N+1,2] f64   the same at horizon h_k-j, j = N-t;
  *                               mode 0: zero, 1: V[i0], 2: f32(V[i0]*w0 + V[i1]*w1) evaluated in float64
- * workspace: ppo_tvf_returns_workspace_bytes(N, A, ND) bytes.
+ *                               a two-column plan names neighbours: i1 == i0 + 1 (the kernel reads them as a pair)
+ * workspace: ppo_tvf_returns_workspace_bytes(N, A, ND, K, C) bytes, 32-byte aligned.
  * Algorithmic HBM traffic: 4*(N+1)*A*V read + 4*N*A*K written.
  */
-size_t ppo_tvf_returns_workspace_bytes(int N, int A, int ND);
+size_t ppo_tvf_returns_workspace_bytes(int N, int A, int ND, int K, int C);
 int ppo_tvf_returns_f32(const float *rewards, const uint8_t *dones, const float *value_samples, int N, int A, int V,
                         int K, int C, double gamma, const int32_t *n_eff, const int32_t *nd_index,
                         const int32_t *nd_of_n, int max_n, int ND, const int32_t *main_plan, const double *main_w,

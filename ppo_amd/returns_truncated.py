@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["get_return_estimate", "calculate_sampled_return_multi", "interpolation_plan"]
+__all__ = ["get_return_estimate", "calculate_sampled_return_multi", "interpolation_plan", "SampledReturnPlan"]
 
 DISTRIBUTIONS = ("fixed", "exponential", "uniform", "hyperbolic", "quadratic")
 MODES = ("standard", "advanced", "clipped", "adaptive", "mcx", "full")
@@ -98,71 +98,93 @@ def _dev(x, dtype):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(x))).to(device=dev, dtype=dtype).contiguous()
 
 
+class SampledReturnPlan:
+    """Everything of one `_calculate_sampled_return_multi_fast` call that does not depend on the [N, A] data, resolved
+    on the host and uploaded: the clipped n-step per (k, c), the prefix-cache slots, and every `_interpolate` call as
+    (mode, columns, float64 weights).  `launch(rewards, dones, value_samples, out)` is then one C-ABI call
+    (bench.py times exactly that)."""
+
+    def __init__(self, N, A, required_horizons, value_sample_horizons, n_step_samples, use_log_interpolation=False,
+                 device=None):
+        self.lib = _lib.load()
+        hz_req = np.asarray(required_horizons).astype(np.int64).reshape(-1)
+        hz_val = np.asarray(value_sample_horizons).astype(np.int64).reshape(-1)
+        K, V = len(hz_req), len(hz_val)
+        samples = np.asarray(n_step_samples).astype(np.int64)
+        if samples.ndim != 2 or samples.shape[0] != K:
+            raise ValueError(f"n_step_samples must be [K={K}, C], got {samples.shape}")
+        C = samples.shape[1]
+        live = hz_req > 0
+        n_eff = np.minimum(samples, np.maximum(hz_req, 1)[:, None])  # n clipped to the horizon (:590-591)
+        if live.any() and (n_eff[live].min() < 1 or n_eff[live].max() > N):
+            raise AssertionError("n-step samples must satisfy 1 <= n <= N")  # the reference asserts (:597)
+        n_eff = np.clip(n_eff, 1, N)
+        max_n = int(n_eff.max())
+        used = np.unique(n_eff)
+        nd_of_n = np.full(max_n + 1, -1, np.int32)
+        nd_of_n[used] = np.arange(len(used), dtype=np.int32)
+        nd_index = nd_of_n[n_eff]
+        axis = (np.log10(10 + hz_val) - 1) if use_log_interpolation else hz_val
+
+        def plan(target):
+            return interpolation_plan(axis, (np.log10(10 + target) - 1) if use_log_interpolation else target)
+
+        main_plan = np.zeros((K, C, 3), np.int32)
+        main_w = np.zeros((K, C, 2), np.float64)
+        tail_plan = np.zeros((K, N + 1, 3), np.int32)
+        tail_w = np.zeros((K, N + 1, 2), np.float64)
+        for k in range(K):
+            if not live[k]:
+                continue
+            h = int(hz_req[k])
+            for c in range(C):
+                m, i0, i1, w0, w1 = plan(h - int(n_eff[k, c]))
+                main_plan[k, c] = (m, i0, i1)
+                main_w[k, c] = (w0, w1)
+            for j in range(1, min(int(n_eff[k].max()), N) + 1):  # only rows t >= N - n ever use the tail
+                m, i0, i1, w0, w1 = plan(h - j)
+                tail_plan[k, j] = (m, i0, i1)
+                tail_w[k, j] = (w0, w1)
+        two = main_plan[..., 0] == 2  # the kernel reads a two-column plan as one paired LDS read of (i0, i0 + 1)
+        two_t = tail_plan[..., 0] == 2
+        assert (main_plan[..., 2][two] == main_plan[..., 1][two] + 1).all() and \
+            (tail_plan[..., 2][two_t] == tail_plan[..., 1][two_t] + 1).all(), "two-column plans must name neighbours"
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.N, self.A, self.K, self.V, self.C, self.max_n, self.ND = N, A, K, V, C, max_n, len(used)
+        self.tables = [up(n_eff.astype(np.int32)), up(nd_index.astype(np.int32)), up(nd_of_n)]
+        self.plans = [up(main_plan), up(main_w), up(tail_plan), up(tail_w), up((~live).astype(np.uint8))]
+        self.ws_bytes = self.lib.ppo_tvf_returns_workspace_bytes(N, A, self.ND, K, C)
+        self.ws = torch.empty((self.ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        self.device = dev
+
+    def launch(self, gamma, r, d, vs, out):
+        p = lambda t: t.data_ptr()  # noqa: E731
+        t_n_eff, t_nd_index, t_nd_of_n = self.tables
+        t_mp, t_mw, t_tp, t_tw, t_kz = self.plans
+        rc = self.lib.ppo_tvf_returns_f32(p(r), p(d), p(vs), self.N, self.A, self.V, self.K, self.C, float(gamma),
+                                          p(t_n_eff), p(t_nd_index), p(t_nd_of_n), self.max_n, self.ND, p(t_mp), p(t_mw),
+                                          p(t_tp), p(t_tw), p(t_kz), p(self.ws), self.ws_bytes, p(out),
+                                          _lib.current_stream())
+        _lib.check(rc, "ppo_tvf_returns_f32")
+        return out
+
+
 def calculate_sampled_return_multi(gamma, rewards, dones, required_horizons, value_sample_horizons, value_samples,
                                    n_step_samples, use_log_interpolation=False):
     """[N, A, K] float32 returns for an explicit sample matrix n_step_samples [K, C]
     (the reference's _calculate_sampled_return_multi_fast)."""
     _lib.require_gpu()
-    lib = _lib.load()
     as_numpy = not isinstance(rewards, torch.Tensor)
     r = _dev(rewards, torch.float32)
     N, A = r.shape
     d = _dev(dones, torch.bool).view(torch.uint8)
     vs = _dev(value_samples, torch.float32)
-    hz_req = np.asarray(required_horizons).astype(np.int64).reshape(-1)
-    hz_val = np.asarray(value_sample_horizons).astype(np.int64).reshape(-1)
-    K, V = len(hz_req), len(hz_val)
+    K, V = len(np.asarray(required_horizons).reshape(-1)), len(np.asarray(value_sample_horizons).reshape(-1))
     if tuple(vs.shape) != (N + 1, A, V) or tuple(d.shape) != (N, A):
         raise ValueError(f"shape mismatch: rewards {tuple(r.shape)}, dones {tuple(d.shape)}, value_samples {tuple(vs.shape)}")
-    samples = np.asarray(n_step_samples).astype(np.int64)
-    if samples.ndim != 2 or samples.shape[0] != K:
-        raise ValueError(f"n_step_samples must be [K={K}, C], got {samples.shape}")
-    C = samples.shape[1]
-    live = hz_req > 0
-    n_eff = np.minimum(samples, np.maximum(hz_req, 1)[:, None])  # n clipped to the horizon (:590-591)
-    if live.any() and (n_eff[live].min() < 1 or n_eff[live].max() > N):
-        raise AssertionError("n-step samples must satisfy 1 <= n <= N")  # the reference asserts (:597)
-    n_eff = np.clip(n_eff, 1, N)
-    max_n = int(n_eff.max())
-    used = np.unique(n_eff)
-    nd_of_n = np.full(max_n + 1, -1, np.int32)
-    nd_of_n[used] = np.arange(len(used), dtype=np.int32)
-    nd_index = nd_of_n[n_eff]
-    axis = (np.log10(10 + hz_val) - 1) if use_log_interpolation else hz_val
-
-    def plan(target):
-        return interpolation_plan(axis, (np.log10(10 + target) - 1) if use_log_interpolation else target)
-
-    main_plan = np.zeros((K, C, 3), np.int32)
-    main_w = np.zeros((K, C, 2), np.float64)
-    tail_plan = np.zeros((K, N + 1, 3), np.int32)
-    tail_w = np.zeros((K, N + 1, 2), np.float64)
-    for k in range(K):
-        if not live[k]:
-            continue
-        h = int(hz_req[k])
-        for c in range(C):
-            m, i0, i1, w0, w1 = plan(h - int(n_eff[k, c]))
-            main_plan[k, c] = (m, i0, i1)
-            main_w[k, c] = (w0, w1)
-        for j in range(1, min(int(n_eff[k].max()), N) + 1):  # only rows t >= N - n ever use the tail
-            m, i0, i1, w0, w1 = plan(h - j)
-            tail_plan[k, j] = (m, i0, i1)
-            tail_w[k, j] = (w0, w1)
-    dev = r.device
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    t_n_eff, t_nd_index, t_nd_of_n = up(n_eff.astype(np.int32)), up(nd_index.astype(np.int32)), up(nd_of_n)
-    t_mp, t_mw, t_tp, t_tw = up(main_plan), up(main_w), up(tail_plan), up(tail_w)
-    t_kz = up((~live).astype(np.uint8))
-    ND = len(used)
-    ws_bytes = lib.ppo_tvf_returns_workspace_bytes(N, A, ND)
-    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-    out = torch.empty((N, A, K), dtype=torch.float32, device=dev)
-    p = lambda t: t.data_ptr()  # noqa: E731
-    rc = lib.ppo_tvf_returns_f32(p(r), p(d), p(vs), N, A, V, K, C, float(gamma), p(t_n_eff), p(t_nd_index), p(t_nd_of_n),
-                                 max_n, ND, p(t_mp), p(t_mw), p(t_tp), p(t_tw), p(t_kz), p(ws), ws_bytes, p(out),
-                                 _lib.current_stream())
-    _lib.check(rc, "ppo_tvf_returns_f32")
+    plan = SampledReturnPlan(N, A, required_horizons, value_sample_horizons, n_step_samples, use_log_interpolation, r.device)
+    out = plan.launch(gamma, r, d, vs, torch.empty((N, A, K), dtype=torch.float32, device=r.device))
     return out.cpu().numpy() if as_numpy else out
 
 

@@ -132,7 +132,10 @@ class Runner:
         # ---- optimisers (rl/rollout.py:126-141)
         self.policy_optimizer = Optimizer(self.policy_net, args.policy_opt)
         self.value_optimizer = Optimizer(self.value_net, args.value_opt) if self.dual else self.policy_optimizer
-        self.distil_optimizer = Optimizer(self.policy_net, args.distil_opt, AdamState()) if self.dual else None
+        # as the reference (rl/rollout.py:145-148): present whenever the distil phase has its own optimiser configured,
+        # whatever the architecture (only `dual` ever steps it; its moment buffers are allocated on first use)
+        own_distil = args.distil_opt.epochs > 0 and not args.distil.use_policy_opt
+        self.distil_optimizer = Optimizer(self.policy_net, args.distil_opt, AdamState()) if own_distil else None
         # ---- device scratch
         self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
         self._moments_ws = torch.zeros(self.lib.ppo_moments_workspace_bytes() // 8, dtype=torch.float64, device=dev)

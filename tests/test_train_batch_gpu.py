@@ -91,7 +91,6 @@ def test_train_batch_micro_batches_accumulate_to_the_same_update():
     assert [c["micro_batch"] for c in seen] == [0, 1, 2, 3, 0, 1, 2, 3] and seen[0]["is_first"] and seen[-1]["is_last"]
     torch.cuda.synchronize()
     # Adam's first steps move a weight by ~lr * g / (|g| + eps): where |g| ~ eps = 1e-5 a rounding difference of the
-    # gradient is amplified to a fraction of a learning-rate step; everywhere else the updates coincide
     # gradient (see the test above: equal to float32 round-off, ~1e-8 absolute) is amplified to a fraction of a
     # learning-rate step.  So: a loose bar on those weights, a tight one wherever the gradient is well above eps
     # (|exp_avg| after two steps ~ 0.19 |g|), and the moments themselves to round-off.
@@ -101,7 +100,8 @@ def test_train_batch_micro_batches_accumulate_to_the_same_update():
     clear = ref.net.exp_avg.abs() > 2e-4  # |g| >~ 1e-3 = 100 eps
     assert int(clear.sum()) > 1000
     assert float(d[clear].max()) < 1e-3 * lr, "a weight with a clear gradient moved differently"
-    assert rel(split.net.exp_avg, ref.net.exp_avg) < 1e-5, "accumulated gradient differs from the one-pass gradient"
+    # (the second step's gradient is taken at weights that already differ by those amplified roundings)
+    assert rel(split.net.exp_avg, ref.net.exp_avg) < 5e-5, "accumulated gradient differs from the one-pass gradient"
 
     # a hook that stops the epoch: no optimiser step for that minibatch
     stop = make()
