@@ -133,8 +133,17 @@ __global__ __launch_bounds__(256) void tvf_gather_kernel(const float *__restrict
 // The plan as 32-byte records, so that a sample's whole plan is ONE scalar load (x8) instead of five from five
 // arrays with a wait between them, and a lane's tail plan two 16-byte loads.  Packed by a small launch in front of the
 // column kernel, into the caller's workspace.
-struct alignas(32) MainRec {
-    int32_t n, nd, mode, i0;
+struct alignas(16) MainRec {  // everything a term needs as ready-made LDS byte offsets: no scalar arithmetic per term
+    int32_t off_sd;  // nd * T * 8: the (S, D) row of this n in the chunk table
+    int32_t off_v;   // (n * VS + i0) * 4: from a lane's row t to V[t + n, i0]
+    int32_t lim;     // (N * VS + i0) * 4: the same column of the last row V[N] - the clamp of off_v + row
+    int32_t thr;     // N - n: rows t >= thr bootstrap from V[N] (their tail plan) instead
+    double w0, w1;
+    int32_t mode, pad0, pad1, pad2;
+};
+struct alignas(8) LaneRec {  // the same, 24 bytes: kept in vector registers, one record per lane (see the kernel)
+    uint32_t a;  // off_sd | thr << 16
+    uint32_t b;  // off_v | mode << 24            (lim = off_v + thr * VS * 4)
     double w0, w1;
 };
 struct alignas(32) TailRec {
@@ -147,14 +156,25 @@ __global__ __launch_bounds__(256) void tvf_pack_kernel(const int32_t *__restrict
                                                        const double *__restrict__ main_w,
                                                        const int32_t *__restrict__ tail_plan,
                                                        const double *__restrict__ tail_w, int n_main, int n_tail,
-                                                       MainRec *__restrict__ mrec, TailRec *__restrict__ trec)
+                                                       int N, int VS, int T, MainRec *__restrict__ mrec,
+                                                       LaneRec *__restrict__ lrec, TailRec *__restrict__ trec)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_main) {
         MainRec r;
-        r.n = n_eff[i], r.nd = nd_index[i], r.mode = main_plan[3 * i], r.i0 = main_plan[3 * i + 1];
+        const int n = n_eff[i], i0 = main_plan[3 * i + 1];
+        r.off_sd = nd_index[i] * T * 8;
+        r.off_v = (n * VS + i0) * 4;
+        r.lim = (N * VS + i0) * 4;
+        r.thr = N - n;
+        r.mode = main_plan[3 * i], r.pad0 = r.pad1 = r.pad2 = 0;
         r.w0 = main_w[2 * i], r.w1 = main_w[2 * i + 1];
         mrec[i] = r;
+        LaneRec l;
+        l.a = (uint32_t)r.off_sd | (uint32_t)r.thr << 16;
+        l.b = (uint32_t)r.off_v | (uint32_t)r.mode << 24;
+        l.w0 = r.w0, l.w1 = r.w1;
+        lrec[i] = l;
     } else if (i < n_main + n_tail) {
         const int j = i - n_main;
         TailRec r;
@@ -210,8 +230,8 @@ struct ColumnArgs {  // the scalars; the pointers stay separate __restrict__ par
 template <int MAXR>  // result registers per lane: K <= MAXR * kColumnWaves
 __global__ __launch_bounds__(kColumnThreads) void tvf_column_kernel(
     const float *__restrict__ rewards, const uint8_t *__restrict__ dones, const float *__restrict__ values,
-    const int32_t *__restrict__ nd_of_n, const MainRec *__restrict__ mrec, const TailRec *__restrict__ trec,
-    const uint8_t *__restrict__ k_zero, float *__restrict__ out, const ColumnArgs p)
+    const int32_t *__restrict__ nd_of_n, const MainRec *__restrict__ mrec, const LaneRec *__restrict__ lrec,
+    const TailRec *__restrict__ trec, const uint8_t *__restrict__ k_zero, float *__restrict__ out, const ColumnArgs p)
 {
 #pragma clang fp contract(off)
     extern __shared__ float lds[];
@@ -284,12 +304,31 @@ __global__ __launch_bounds__(kColumnThreads) void tvf_column_kernel(
         if (k >= K || k_zero[k]) kz |= 1u << j;
     }
     kz = __builtin_amdgcn_readfirstlane(kz);
+    // This wave's plan records, ONE PER LANE in vector registers (record j * C + c of the wave in lane (j * C + c) % 64
+    // of register set (j * C + c) / 64), loaded once: a term then gets its record with six v_readlane and no memory
+    // access at all.  As scalar loads they cost one L2 round trip per group of terms - the table (K * C * 48 bytes) is
+    // larger than the scalar cache and every wave streams its own part of it once per chunk - and that round trip,
+    // not instruction issue, set the pace.  Up to kLaneC samples per head; more take the scalar-load path below.
+    constexpr int kLaneC = 8;
+    constexpr int NSET = (MAXR * kLaneC + kWave - 1) / kWave;
+    const bool lane_recs = C <= kLaneC;
+    uint32_t ra[NSET], rb[NSET], rw0l[NSET], rw0h[NSET], rw1l[NSET], rw1h[NSET];
+#pragma unroll
+    for (int s2 = 0; s2 < NSET; ++s2) {
+        const int ri = s2 * kWave + lane;
+        const int j = ri / C, c = ri - j * C;
+        const int k = j * kColumnWaves + wave;
+        const bool ok = lane_recs && j < MAXR && k < K;
+        const LaneRec r = lrec[ok ? (size_t)k * C + c : 0];
+        ra[s2] = r.a, rb[s2] = r.b;
+        rw0l[s2] = (uint32_t)__double2loint(r.w0), rw0h[s2] = (uint32_t)__double2hiint(r.w0);
+        rw1l[s2] = (uint32_t)__double2loint(r.w1), rw1h[s2] = (uint32_t)__double2hiint(r.w1);
+    }
     __syncthreads();
 
-    const uint32_t last_row_b = (uint32_t)N * VS * 4;  // byte offset of V[N] in LDS: the clamp of every row address
     const float *last_row = vals + (size_t)N * VS;
     const bool lane_on = lane < T;
-    const int sd_lane = lane_on ? lane : 0;
+    const char *sd_lane_b = reinterpret_cast<const char *>(sd + (lane_on ? lane : 0));
     for (int t0 = 0; t0 < N; t0 += T) {
         const int t = t0 + lane;
         // ---- walk: S_n[t], D_n[t] at every needed n, reference order (rl/returns_truncated.py:667-672).  The slots of
@@ -374,52 +413,74 @@ __global__ __launch_bounds__(kColumnThreads) void tvf_column_kernel(
             for (int jj = 0; jj < MAXR; ++jj) tb = jj == j ? tail_boot[jj] : tb;
             if (!((kz >> j) & 1u) && !(p.skip & 2)) {
                 // one term: boot from the pair (V[t+n, i0], V[t+n, i0+1]) - a two-column plan always names neighbours
-                auto term = [&](int n, int mode, double w0, double w1, float2 e, float2 v) {
+                auto term = [&](const MainRec &r, float2 e, float2 v) {
                     float boot;
-                    if (mode == 0) {  // uniform branches: the operands are already here
-                        boot = 0.f;
-                    } else if (mode == 1) {
-                        boot = v.x;
-                    } else {
-                        const double x0 = (double)v.x * w0;
-                        const double x1 = (double)v.y * w1;
+                    if (r.mode == 2) {  // uniform branches: the operands are already here
+                        const double x0 = (double)v.x * r.w0;
+                        const double x1 = (double)v.y * r.w1;
                         boot = (float)(x0 + x1);
+                    } else {
+                        boot = r.mode == 1 ? v.x : 0.f;
                     }
-                    if (t_hi >= N - n) boot = t >= N - n ? tb : boot;  // uniform test, then per lane
+                    if (t_hi >= r.thr) boot = t >= r.thr ? tb : boot;  // uniform test, then per lane
                     const float md = boot * e.y;
                     const float tm = e.x + md;
                     total = total + tm;
                 };
-                auto read_pair = [&](int n, int i0) {
-                    uint32_t addr = row_t + (uint32_t)(n * VS + i0) * 4;
-                    addr = addr < last_row_b + (uint32_t)i0 * 4 ? addr : last_row_b + (uint32_t)i0 * 4;
+                auto read_sd = [&](const MainRec &r) {
+                    return *reinterpret_cast<const float2 *>(sd_lane_b + r.off_sd);
+                };
+                auto read_pair = [&](const MainRec &r) {
+                    uint32_t addr = row_t + (uint32_t)r.off_v;
+                    addr = addr < (uint32_t)r.lim ? addr : (uint32_t)r.lim;
                     const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(vals) + addr);
                     return make_float2(q[0], q[1]);
                 };
-                int c = 0;
-                for (; c + 4 <= C; c += 4) {
-                    MainRec r[4];
-                    float2 e[4], v[4];
+                auto lane_rec = [&](int ri) {  // record ri of this wave out of the lanes
+                    MainRec r;
+                    uint32_t a = 0, b = 0, w0l = 0, w0h = 0, w1l = 0, w1h = 0;
+                    const int ln = ri & (kWave - 1);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) r[u] = mrec[k * C + c + u];
-                    // pin all four records' weights at ONE point: otherwise their loads sink into the blends' branches, and
-                    // pinned one by one each record gets a wait of its own (scalar loads return out of order: every wait
-                    // is lgkmcnt(0))
-                    asm volatile("" : "+s"(r[0].w0), "+s"(r[0].w1), "+s"(r[1].w0), "+s"(r[1].w1), "+s"(r[2].w0), "+s"(r[2].w1),
-                                 "+s"(r[3].w0), "+s"(r[3].w1), "+s"(r[0].n), "+s"(r[1].n), "+s"(r[2].n), "+s"(r[3].n));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        e[u] = sd[r[u].nd * T + sd_lane];
-                        v[u] = read_pair(r[u].n, r[u].i0);
+                    for (int s2 = 0; s2 < NSET; ++s2) {
+                        if (NSET == 1 || (ri >> 6) == s2) {  // uniform
+                            a = __builtin_amdgcn_readlane(ra[s2], ln), b = __builtin_amdgcn_readlane(rb[s2], ln);
+                            w0l = __builtin_amdgcn_readlane(rw0l[s2], ln), w0h = __builtin_amdgcn_readlane(rw0h[s2], ln);
+                            w1l = __builtin_amdgcn_readlane(rw1l[s2], ln), w1h = __builtin_amdgcn_readlane(rw1h[s2], ln);
+                        }
                     }
+                    r.off_sd = (int32_t)(a & 0xffffu);
+                    r.thr = (int32_t)(a >> 16);
+                    r.off_v = (int32_t)(b & 0xffffffu);
+                    r.mode = (int32_t)(b >> 24);
+                    r.lim = r.off_v + r.thr * VS * 4;
+                    r.w0 = __hiloint2double((int)w0h, (int)w0l);
+                    r.w1 = __hiloint2double((int)w1h, (int)w1l);
+                    return r;
+                };
+                int c = 0;
+                if (lane_recs) {
+                    for (; c + 4 <= C; c += 4) {
+                        MainRec r[4];
+                        float2 e[4], v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) term(r[u].n, r[u].mode, r[u].w0, r[u].w1, e[u], v[u]);
+                        for (int u = 0; u < 4; ++u) r[u] = lane_rec(j * C + c + u);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            e[u] = read_sd(r[u]);
+                            v[u] = read_pair(r[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) term(r[u], e[u], v[u]);
+                    }
+                    for (; c < C; ++c) {
+                        const MainRec r = lane_rec(j * C + c);
+                        term(r, read_sd(r), read_pair(r));
+                    }
                 }
+                const MainRec *mk = mrec + (size_t)k * C;  // more than kLaneC samples per head: records by scalar loads
                 for (; c < C; ++c) {
-                    const MainRec r = mrec[k * C + c];
-                    const float2 e = sd[r.nd * T + sd_lane];
-                    const float2 v = read_pair(r.n, r.i0);
-                    term(r.n, r.mode, r.w0, r.w1, e, v);
+                    const MainRec r = mk[c];
+                    term(r, read_sd(r), read_pair(r));
                 }
                 total = total * p.inv_c;
             }
@@ -444,8 +505,8 @@ __global__ __launch_bounds__(kColumnThreads) void tvf_column_kernel(
 
 template <int MAXR>
 int launch_column(const ColumnLds &L, hipStream_t st, const float *rewards, const uint8_t *dones, const float *values,
-                  const int32_t *nd_of_n, const MainRec *mrec, const TailRec *trec, const uint8_t *k_zero, float *out,
-                  ColumnArgs args)
+                  const int32_t *nd_of_n, const MainRec *mrec, const LaneRec *lrec, const TailRec *trec,
+                  const uint8_t *k_zero, float *out, ColumnArgs args)
 {
     auto kern = tvf_column_kernel<MAXR>;
     // timing aid (tools/tvf_phases.sh): bit 0 skips the walk, 1 the terms, 2 the stores - results are then garbage
@@ -464,8 +525,8 @@ int launch_column(const ColumnLds &L, hipStream_t st, const float *rewards, cons
     args.need_off = (int)L.need_off;
     args.sd_off = (int)L.sd_off;
     args.skip = skip;
-    hipLaunchKernelGGL(kern, dim3(args.A), dim3(kColumnThreads), L.bytes, st, rewards, dones, values, nd_of_n, mrec, trec,
-                       k_zero, out, args);
+    hipLaunchKernelGGL(kern, dim3(args.A), dim3(kColumnThreads), L.bytes, st, rewards, dones, values, nd_of_n, mrec, lrec,
+                       trec, k_zero, out, args);
     return check_launch("tvf_column_kernel");
 }
 
@@ -475,7 +536,7 @@ int launch_column(const ColumnLds &L, hipStream_t st, const float *rewards, cons
 extern "C" size_t ppo_tvf_returns_workspace_bytes(int N, int A, int ND, int K, int C)
 {
     // the larger of: the packed plan records of the column kernel; the [nd][t, a] S / D cache of the fallback kernels
-    const size_t records = ((size_t)K * C + (size_t)K * (N + 1)) * 32;
+    const size_t records = (size_t)K * C * (48 + 24) + (size_t)K * (N + 1) * 32 + 32;
     const size_t cache = (size_t)2 * N * A * (ND < 1 ? 1 : ND) * sizeof(float);
     return records > cache ? records : cache;
 }
@@ -510,14 +571,16 @@ extern "C" int ppo_tvf_returns_f32(const float *rewards, const uint8_t *dones, c
             ca.inv_c = (float)(1.0 / C);
             const int n_main = K * C, n_tail = K * (N + 1);
             MainRec *mrec = static_cast<MainRec *>(workspace);
-            TailRec *trec = reinterpret_cast<TailRec *>(mrec + n_main);
+            LaneRec *lrec = reinterpret_cast<LaneRec *>(mrec + n_main);
+            TailRec *trec = reinterpret_cast<TailRec *>(
+                (reinterpret_cast<uintptr_t>(lrec + n_main) + 31) & ~(uintptr_t)31);
             hipLaunchKernelGGL(tvf_pack_kernel, dim3((n_main + n_tail + 255) / 256), dim3(256), 0, st, n_eff, nd_index,
-                               main_plan, main_w, tail_plan, tail_w, n_main, n_tail, mrec, trec);
+                               main_plan, main_w, tail_plan, tail_w, n_main, n_tail, N, L.VS, L.T, mrec, lrec, trec);
             int rc = check_launch("tvf_pack_kernel");
             if (rc) return rc;
             return K <= 8 * kColumnWaves
-                       ? launch_column<8>(L, st, rewards, dones, value_samples, nd_of_n, mrec, trec, k_zero, out, ca)
-                       : launch_column<16>(L, st, rewards, dones, value_samples, nd_of_n, mrec, trec, k_zero, out, ca);
+                       ? launch_column<8>(L, st, rewards, dones, value_samples, nd_of_n, mrec, lrec, trec, k_zero, out, ca)
+                       : launch_column<16>(L, st, rewards, dones, value_samples, nd_of_n, mrec, lrec, trec, k_zero, out, ca);
         }
     }
     float *cS = static_cast<float *>(workspace);

@@ -92,3 +92,25 @@ def test_edges_zero_horizon_all_done_and_errors():
         R.calculate_sampled_return_multi(0.97, rewards, np.zeros((N, A), bool), np.asarray([40]), hz_v, vs, np.asarray([[1]]))
     with pytest.raises(ValueError):
         R.calculate_sampled_return_multi(0.97, rewards, np.zeros((N, A + 1), bool), hz_r, hz_v, vs, np.ones((4, 1), int))
+
+
+@pytest.mark.parametrize("N,A,K,C,what", [
+    (40, 7, 12, 3, "remainder loop of the lane-resident records (C not a multiple of 4)"),
+    (40, 7, 12, 12, "more than 8 samples per head: records by scalar loads"),
+    (64, 5, 140, 8, "more than 128 heads: 16 result registers per lane, two register sets of records"),
+    (300, 3, 20, 4, "N not a multiple of the chunk: partial last chunk, idle lanes"),
+    (700, 2, 64, 2, "a column that does not fit in LDS: the prefix + gather fallback kernels"),
+])
+def test_kernel_paths_bit_exact_vs_oracle(N, A, K, C, what):
+    """Every code path of csrc/tvf_returns.hip against the NumPy oracle, bit for bit."""
+    rng = np.random.default_rng(N * 1000 + K)
+    hz = np.unique(np.concatenate([[0, 1, 2, 3], np.geomspace(4, 5000, K - 4).astype(np.int64)]))
+    hz = np.concatenate([hz, hz[-1] + 1 + np.arange(K - len(hz))]).astype(np.int64)  # K distinct, increasing
+    assert len(hz) == K and (np.diff(hz) > 0).all()
+    rewards = rng.normal(size=(N, A)).astype(np.float32)
+    dones = rng.random((N, A)) < 0.03
+    vs = rng.normal(size=(N + 1, A, K)).astype(np.float32)
+    samples = rng.integers(1, min(N, 90) + 1, size=(K, C))
+    out = R.calculate_sampled_return_multi(0.99, rewards, dones, hz, hz, vs, samples)
+    ref = T.sampled_returns(0.99, rewards, dones, hz, hz, vs, samples)
+    assert np.array_equal(out, ref), (what, np.abs(out - ref).max())
