@@ -50,12 +50,35 @@ FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_bench_hbm_traffic.json")
 
 
+# BASELINE.json `configs`, as synthetic workloads of the named shape (synthetic rollouts; the simulators
+# are not installed).  `pong` is the configuration the headline metric is quoted on and the default line.
+CONFIGS = {
+    "pong": dict(agents=256, obs=(4, 84, 84), actions=6, dist="discrete", metric="env-steps/sec (Pong-shaped synthetic, 256 envs/GPU)",
+                 flags=["--model_architecture=single", "--model_encoder=impala", "--env_type=synthetic",
+                        "--env_embed_time=False", "--policy_opt_epochs=2"]),
+    "procgen": dict(agents=1024, obs=(3, 64, 64), actions=15, dist="discrete",
+                    metric="env-steps/sec (Procgen-shaped synthetic, 1024 envs/GPU)",
+                    flags=["--model_architecture=single", "--model_encoder=impala", "--env_type=synthetic",
+                           "--env_synthetic_shape=3,64,64", "--env_synthetic_actions=15", "--env_embed_time=False",
+                           "--policy_opt_epochs=2"]),
+    "humanoid_tvf": dict(agents=256, obs=(377,), actions=17, dist="gaussian",
+                         metric="env-steps/sec (Humanoid-shaped synthetic, 256 envs/GPU, MLP + TVF)",
+                         flags=["--model_architecture=dual", "--model_encoder=mlp", "--model_hidden_units=256",
+                                "--env_type=mujoco", "--env_name=Humanoid", "--tvf_enabled=True", "--tvf_value_heads=128",
+                                "--tvf_max_horizon=30000", "--value_opt_mini_batch_size=256",
+                                "--distil_opt_mini_batch_size=256"]),
+}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--agents", type=int, default=256, help="envs per GPU")
+    p.add_argument("--config", default="pong", choices=sorted(CONFIGS),
+                   help="workload: pong = BASELINE.json configs[1] (the driver's line, default); procgen = configs[2]; "
+                        "humanoid_tvf = configs[4]")
+    p.add_argument("--agents", type=int, default=None, help="envs per GPU (default: the config's)")
     p.add_argument("--n-steps", type=int, default=256, help="rollout length N")
     p.add_argument("--scan-envs", type=int, default=1 << 20, help="A of the bandwidth-regime scan")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,6 +291,36 @@ class CallProbe:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over ppo_amd/csrc: what a PMC traffic record must have been measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ppo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def forward_mflop(obs_shape, n_actions, hidden, config):
+    """Algorithmic forward MFLOP per sample: 2 * 9 * Cin * Cout per output pixel of every convolution
+    of the IMPALA encoder (3 stacks of 16 / 32 / 32 channels: first convolution at the input size, 3x3/s2 max-pool, two
+    residual blocks of two convolutions) + the dense layer; MLP: the two dense layers + heads."""
+    if len(obs_shape) == 1:
+        heads = 2 * n_actions + 1 + (128 if config == "humanoid_tvf" else 0)
+        return 2.0 * (obs_shape[0] * hidden + hidden * hidden + hidden * heads) / 1e6
+    c, h, w = obs_shape
+    total = 0.0
+    for cout in (16, 32, 32):
+        total += 2.0 * 9 * c * cout * h * w
+        h, w = _half(h), _half(w)
+        total += 4 * 2.0 * 9 * cout * cout * h * w
+        c = cout
+    total += 2.0 * c * h * w * hidden
+    return total / 1e6
+
+
 def _conv(n, cin, cout, h, w):
     return 2.0 * 9 * cin * cout * h * w * n
 
@@ -278,7 +331,32 @@ def _half(x):
 
 # entry point -> (label, algorithmic FLOPs, algorithmic HBM bytes) of one launch, from the C-ABI arguments
 # (include/ppo_amd.h).  FLOPs bound the MFMA kernels, bytes the streaming ones; neither => latency-bound helper.
-def describe_call(fn, a):
+def describe_call(fn, a, train_batch=256):
+    label, flops, nbytes = _describe_call(fn, a)
+    n = _batch_of(fn, a)
+    if n is not None and n != train_batch:
+        label += f" [n={n}]"  # rollout-geometry launches (half-batch env groups) listed beside the training ones
+    return label, flops, nbytes
+
+
+def _batch_of(fn, a):
+    if fn in ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32", "ppo_conv3x3_pool_forward_f32",
+              "ppo_conv3x3_pool_forward_packed_f32"):
+        return a[6]
+    if fn == "ppo_impala_stack_tail_forward_f32":
+        return a[7]
+    if fn == "ppo_impala_stack_full_forward_f32":
+        return a[9]
+    if fn == "ppo_impala_stack_chain_forward_f32":
+        return a[15]
+    if fn == "ppo_impala_stack16_forward_f32":
+        return a[-4]
+    if fn == "ppo_dense_heads_forward_f32":
+        return a[9]
+    return None
+
+
+def _describe_call(fn, a):
     f32 = 4
     if fn in ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32"):
         n, ci, co, h, w = a[6:11]
@@ -353,8 +431,9 @@ class KernelTable:
     kernel class.  Durations of kernels that share the chip with another stream's kernels (backward-data next to
     the weight gradients; the two rollout groups) include that sharing, as in a rocprofv3 trace."""
 
-    def __init__(self, objs):
+    def __init__(self, objs, train_batch=256):
         self.rows = {}
+        self.train_batch = train_batch
         self._undo = []
         for o in objs:
             orig = o._call
@@ -369,7 +448,7 @@ class KernelTable:
             e0.record()
             orig(fn_name, *a)
             e1.record()
-            label, flops, nbytes = describe_call(fn_name, a)
+            label, flops, nbytes = describe_call(fn_name, a, self.train_batch)
             row = self.rows.setdefault(label, {"events": [], "flops": 0.0, "bytes": 0.0})
             row["events"].append((e0, e1))
             row["flops"] += flops or 0.0
@@ -380,7 +459,7 @@ class KernelTable:
         for o, orig in self._undo:
             o._call = orig
 
-    def table(self, top=24):
+    def table(self, top=32):
         out, total = [], 0.0
         for label, row in self.rows.items():
             ms = sum(a.elapsed_time(b) for a, b in row["events"])
@@ -509,7 +588,7 @@ def bench_tvf(K_heads=108, N=256, A=256, reps=20):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(N, A, epochs, mb):
+def cpu_baseline(N, A, epochs, mb, obs_shape=(4, 84, 84), n_actions=6):
     """The PPO iteration on the host through plain torch CPU ops (oracle/model_torch.py), bounded: one rollout
     forward of `A` observations and one train minibatch of `mb` samples (the GPU workload's own batch sizes) are
     timed, then extrapolated to a full iteration of N*A env steps."""
@@ -519,12 +598,12 @@ def cpu_baseline(N, A, epochs, mb):
     from ppo_amd.models import ImpalaSpec, init_impala_parameters
     threads = torch.get_num_threads()
     torch.manual_seed(1)
-    init = init_impala_parameters(ImpalaSpec((4, 84, 84)), 6, 1, 0.1, True)
+    init = init_impala_parameters(ImpalaSpec(tuple(obs_shape)), n_actions, 1, 0.1, True)
     fb, tb = A, mb
     rng = np.random.default_rng(0)
-    xf = torch.from_numpy(rng.integers(0, 256, (fb, 4, 84, 84), dtype=np.uint8))
-    xt = torch.from_numpy(rng.integers(0, 256, (tb, 4, 84, 84), dtype=np.uint8))
-    actions = torch.from_numpy(rng.integers(0, 6, (tb,)))
+    xf = torch.from_numpy(rng.integers(0, 256, (fb, *obs_shape), dtype=np.uint8))
+    xt = torch.from_numpy(rng.integers(0, 256, (tb, *obs_shape), dtype=np.uint8))
+    actions = torch.from_numpy(rng.integers(0, n_actions, (tb,)))
     lpac = torch.full((tb,), -1.79)
     adv = torch.from_numpy(rng.normal(size=(tb,)).astype(np.float32))
     ret = torch.from_numpy(rng.normal(size=(tb, 1)).astype(np.float32))
@@ -585,7 +664,8 @@ def main():
     from ppo_amd import _lib, envs, logger, models, parallel, rollout
     from ppo_amd.config import args
     lib = _lib.load()
-    N, A = a.n_steps, a.agents
+    cfg = CONFIGS[a.config]
+    N, A = a.n_steps, a.agents or cfg["agents"]
     if a.scan_only:
         print(json.dumps({"gae_scan": bench_scan(lib, N, a.scan_envs, A)}), flush=True)
         return 0
@@ -593,38 +673,62 @@ def main():
         print(json.dumps({"tvf_returns": bench_tvf(a.tvf_heads)}), flush=True)
         return 0
     mb = 256
-    args.setup([f"--agents={A}", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala",
-                "--env_type=synthetic", "--env_embed_time=False", "--seed=1", f"--device=cuda:{local}",
-                f"--policy_opt_mini_batch_size={mb * world}", "--policy_opt_epochs=2", "--disable_logging=True",
-                "--upload_batch=True", "--env_reward_normalization=off"])
+    args.setup([f"--agents={A}", f"--n_steps={N}", *cfg["flags"], "--seed=1", f"--device=cuda:{local}",
+                f"--policy_opt_mini_batch_size={mb * world}", "--disable_logging=True", "--upload_batch=True",
+                "--env_reward_normalization=off"])
     torch.manual_seed(1)
     np.random.seed(1 + rank)
-    obs_shape, n_actions = envs.get_env_spec()
-    model = models.TVFModel(encoder="impala", input_dims=obs_shape, actions=n_actions, device=f"cuda:{local}",
-                            architecture="single", hidden_units=args.model.hidden_units, head_scale=args.model.head_scale,
-                            head_bias=args.model.head_bias)
-    runner = rollout.Runner(model, logger.Logger(quiet=True))
-    runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
+    if a.config == "humanoid_tvf":
+        # the float / gaussian synthetic env in the Humanoid's shape, as two array-stepping groups (pipelined rollout)
+        from ppo_amd import tvf as tvf_mod
+        from ppo_amd.vec_env import SplitVecEnv, SyntheticFloatVecEnv
+        obs_shape, n_actions = cfg["obs"], cfg["actions"]
+        horizons, weights = tvf_mod.get_value_head_horizons(args.tvf.value_heads, args.tvf.max_horizon,
+                                                            args.tvf.head_spacing, include_weight=True)
+        args.tvf.value_heads = len(horizons)
+        model = models.TVFModel(encoder="mlp", input_dims=obs_shape, actions=n_actions, device=f"cuda:{local}",
+                                architecture="dual", hidden_units=args.model.hidden_units, encoder_activation_fn="tanh",
+                                tvf_fixed_head_horizons=horizons, tvf_fixed_head_weights=weights,
+                                head_scale=args.model.head_scale, head_bias=args.model.head_bias)
+        runner = rollout.Runner(model, logger.Logger(quiet=True), action_dist="gaussian")
+        runner.vec_env = SplitVecEnv([SyntheticFloatVecEnv(A // 2, obs_shape[0], n_actions, seed=1,
+                                                           env_offset=rank * A + i * (A // 2)) for i in range(2)])
+    else:
+        obs_shape, n_actions = envs.get_env_spec()
+        assert tuple(obs_shape) == tuple(cfg["obs"]) and n_actions == cfg["actions"], (obs_shape, n_actions)
+        model = models.TVFModel(encoder="impala", input_dims=obs_shape, actions=n_actions, device=f"cuda:{local}",
+                                architecture="single", hidden_units=args.model.hidden_units,
+                                head_scale=args.model.head_scale, head_bias=args.model.head_bias)
+        runner = rollout.Runner(model, logger.Logger(quiet=True))
+        runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
     runner.reset()
     if os.environ.get("PPO_AMD_DUMP_MAPS"):
         # diagnostics for crashes under a profiler: the load addresses that turn a raw stack trace into library + offset
         with open(os.environ["PPO_AMD_DUMP_MAPS"], "w") as f:
             f.write(open("/proc/self/maps").read())
 
-    # The roofline probe: the kernel with the largest share of GPU time in profiles/ — the training forward's chained
-    # LDS-resident launch (residual blocks of the 21x21 stack + the whole 11x11 stack); with the fused paths switched
-    # off (PPO_AMD_FUSE_STACK_TAIL / _CHAIN = 0) it falls back to the stack-tail launch or the single 32->32 21x21
-    # forward convolution.  Only minibatch-sized training launches are timed (n == mb).
-    def probe_match(fn_name, c):
-        if fn_name == "ppo_impala_stack_chain_forward_f32":  # (in, pre_w, pre_b, pre_a0..pre_q1, w, b, pooled, argmax,
-            return c[3] is not None and (c[15], c[16], c[17], c[18]) == (mb, 32, 21, 21)  # a0..q1, n, channels, h, w)
-        if fn_name == "ppo_impala_stack_tail_forward_f32":  # (in, w[4], b[4], a0, q0, a1, q1, n, channels, h, w)
-            return c[3] is not None and (c[7], c[8], c[9], c[10]) == (mb, 32, 21, 21)
-        return c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (mb, 32, 32, 21, 21)
+    # The roofline probe (pong): the kernel with the largest share of GPU time in profiles/ — the training forward's
+    # chained LDS-resident launch (residual blocks of the 21x21 stack + the whole 11x11 stack); with the fused paths
+    # switched off (PPO_AMD_FUSE_STACK_TAIL / _CHAIN = 0) it falls back to the stack-tail launch or the single 32->32
+    # 21x21 forward convolution.  Minibatch-sized training launches (n == mb) and the rollout groups' half-batch launches
+    # (n == A / 2) are timed separately: at half batch the one-workgroup-per-image kernels fill half the chip.
+    # The other configs take their roofline kernel from the per-kernel table below (its largest row).
+    geo = {"pong": (32, 21, 21)}.get(a.config)
 
-    probe = CallProbe(model.policy_net, ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32",
-                                         "ppo_impala_stack_tail_forward_f32", "ppo_impala_stack_chain_forward_f32"),
-                      probe_match)
+    def probe_match_n(n_want):
+        def match(fn_name, c):
+            if geo is None:
+                return False
+            if fn_name == "ppo_impala_stack_chain_forward_f32":  # (in, pre_w, pre_b, pre_a0..pre_q1, w, b, pooled, argmax,
+                return (c[15], c[16], c[17], c[18]) == (n_want, *geo)                 # a0..q1, n, channels, h, w)
+            if fn_name == "ppo_impala_stack_tail_forward_f32":  # (in, w[4], b[4], a0, q0, a1, q1, n, channels, h, w)
+                return (c[7], c[8], c[9], c[10]) == (n_want, *geo)
+            return c[1] == 1 and (c[6], c[7], c[8], c[9], c[10]) == (n_want, 32, *geo)
+        return match
+
+    probe_fns = ("ppo_conv3x3_forward_f32", "ppo_conv3x3_forward_packed_f32", "ppo_impala_stack_tail_forward_f32",
+                 "ppo_impala_stack_chain_forward_f32")
+    probe = CallProbe(model.policy_net, probe_fns, probe_match_n(mb))
     conv_flops = 2 * 9 * 32 * 32 * 21 * 21 * mb
 
     def iteration():
@@ -659,42 +763,66 @@ def main():
     exposed_comm_ms = reducer.exposed_ms() if reducer is not None else None
 
     env_steps = world * N * A * a.steps
-    if not probe.events:
-        raise SystemExit("bench.py: the roofline probe saw no launch of its kernel (entry point renamed?)")
-    kern_ms = probe.avg_ms()
-    map_bytes = 32 * 21 * 21 * 4 * mb
-    small_bytes = 32 * 11 * 11 * 4 * mb
-    if probe.seen == "ppo_impala_stack_chain_forward_f32":
-        # the 21x21 stack's 4 block convolutions, the 11x11 stack's first convolution (on the 21x21 map) + max-pool and
-        # its 4 block convolutions; reads the 21x21 pooled map, writes the 4 + 4 maps the backward pass needs, the
-        # pooled 11x11 map and its uint8 argmax
-        probe_flops = 5 * conv_flops + 4 * (2 * 9 * 32 * 32 * 11 * 11 * mb)
-        probe_bytes = 5 * map_bytes + 5 * small_bytes + small_bytes // 4
-        probe_kernel = ("stack_full_kernel<32,21,21 -> 11,11> chained training forward: residual blocks of the 21x21 stack + "
-                        "the whole 11x11 stack (9 convolutions + max-pool) in one launch, maps resident in LDS "
-                        "(ppo_impala_stack_chain_forward_f32, minibatch launches)")
-        traffic_key = "stack_full_kernel"
-    elif probe.seen == "ppo_impala_stack_tail_forward_f32":   # reads the block input, writes a0, q0, a1, q1
-        probe_flops, probe_bytes = 4 * conv_flops, 5 * map_bytes
-        probe_kernel = ("stack_tail_kernel<32,21,21> training forward: the 4 residual-block convolutions of the 21x21 "
-                        "stack in one launch (ppo_impala_stack_tail_forward_f32, minibatch launches)")
-        traffic_key = "stack_tail_kernel"
-    else:
-        probe_flops, probe_bytes = conv_flops, 2 * map_bytes
-        probe_kernel = "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)"
-        traffic_key = "conv3x3_kernel"
-    traffic, traffic_source = None, "no PMC pass over this command on file (tools/pmc_bench.sh)"
-    if mb == 256 and os.path.exists(TRAFFIC_FILE):
-        rec = json.load(open(TRAFFIC_FILE)).get(traffic_key)
-        if rec:
-            traffic = int(rec["hbm_bytes_per_launch"])
-            traffic_source = os.path.relpath(TRAFFIC_FILE, ROOT) + ": " + rec.get("how", "")
-    tflops = probe_flops / (kern_ms * 1e-3) / 1e12
-    samples_fwd = (N + 1) * A + args.policy_opt.epochs * N * A
-    samples_bwd = args.policy_opt.epochs * N * A
-    model_tflops = (samples_fwd + 2 * samples_bwd) * FWD_MFLOP_PER_SAMPLE * 1e6 * a.steps / wall / 1e12
+    roofline = None
+    if geo is not None:
+        if not probe.events:
+            raise SystemExit("bench.py: the roofline probe saw no launch of its kernel (entry point renamed?)")
+        kern_ms = probe.avg_ms()
+        map_bytes = 32 * 21 * 21 * 4 * mb
+        small_bytes = 32 * 11 * 11 * 4 * mb
+        if probe.seen == "ppo_impala_stack_chain_forward_f32":
+            # the 21x21 stack's 4 block convolutions, the 11x11 stack's first convolution (on the 21x21 map) + max-pool
+            # and its 4 block convolutions; reads the 21x21 pooled map, writes the 4 + 4 maps the backward pass needs,
+            # the pooled 11x11 map and its uint8 argmax
+            probe_flops = 5 * conv_flops + 4 * (2 * 9 * 32 * 32 * 11 * 11 * mb)
+            probe_bytes = 5 * map_bytes + 5 * small_bytes + small_bytes // 4
+            probe_kernel = ("stack_full_kernel<32,21,21 -> 11,11> chained training forward: residual blocks of the 21x21 "
+                            "stack + the whole 11x11 stack (9 convolutions + max-pool) in one launch, maps resident in LDS "
+                            "(ppo_impala_stack_chain_forward_f32, minibatch launches)")
+            traffic_key = "stack_full_kernel"
+        elif probe.seen == "ppo_impala_stack_tail_forward_f32":   # reads the block input, writes a0, q0, a1, q1
+            probe_flops, probe_bytes = 4 * conv_flops, 5 * map_bytes
+            probe_kernel = ("stack_tail_kernel<32,21,21> training forward: the 4 residual-block convolutions of the 21x21 "
+                            "stack in one launch (ppo_impala_stack_tail_forward_f32, minibatch launches)")
+            traffic_key = "stack_tail_kernel"
+        else:
+            probe_flops, probe_bytes = conv_flops, 2 * map_bytes
+            probe_kernel = "conv3x3_kernel<32,32,21,21,IN_RELU> forward (ppo_conv3x3_forward_f32, minibatch launches)"
+            traffic_key = "conv3x3_kernel"
+        traffic, traffic_source = None, "no PMC pass over this command on file (tools/pmc_bench.sh)"
+        if mb == 256 and os.path.exists(TRAFFIC_FILE):
+            doc = json.load(open(TRAFFIC_FILE))
+            rec = doc.get(traffic_key)
+            if rec:
+                # the counters were taken over a particular build of the kernels: say which, and report null when the
+                # kernel sources have changed since (profiles/*_bench_hbm_traffic.json carries their hash)
+                now = kernel_source_hash()
+                if doc.get("kernel_source_sha16") in (None, now):
+                    traffic = int(rec["hbm_bytes_per_launch"])
+                    traffic_source = os.path.relpath(TRAFFIC_FILE, ROOT) + ": " + rec.get("how", "") + (
+                        "" if doc.get("kernel_source_sha16") else " [no kernel-source hash on file: an earlier round's pass]")
+                else:
+                    traffic_source = (f"{os.path.relpath(TRAFFIC_FILE, ROOT)} was measured on kernel sources "
+                                      f"{doc.get('kernel_source_sha16')} (now {now}): stale, not reported")
+        tflops = probe_flops / (kern_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                    # HBM bytes per launch of this kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate
+                    # runs) over this same bench.py command, 2 x FETCH_SIZE + WRITE_SIZE KiB as the guide prescribes
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": probe_bytes, "kernel": probe_kernel,
+                    "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
+                    "launches_timed": len(probe.events)}
+    fwd_mflop = forward_mflop(obs_shape, n_actions, args.model.hidden_units, a.config)
+    epochs_fwd = args.policy_opt.epochs + (args.value_opt.epochs + args.distil_opt.epochs if runner.dual else 0)
+    samples_fwd = (N + 1) * A * (2 if runner.dual else 1) + epochs_fwd * N * A
+    samples_bwd = epochs_fwd * N * A
+    model_tflops = (samples_fwd + 2 * samples_bwd) * fwd_mflop * 1e6 * a.steps / wall / 1e12
+    obs_kind = "uint8" if len(obs_shape) == 3 else "float32"
+    net_kind = ("IMPALA-CNN single architecture" if a.config != "humanoid_tvf" else
+                f"tanh MLP dual architecture (policy + value + distil phases), {args.tvf.value_heads} TVF heads, gaussian policy")
     out = {
-        "metric": "env-steps/sec (Pong-shaped synthetic, 256 envs/GPU)",
+        "metric": cfg["metric"],
         "value": round(env_steps / wall, 1),
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -708,20 +836,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"PPO iteration: {A} envs/GPU x {N} steps, obs {obs_shape} uint8, IMPALA-CNN single "
-                               f"architecture ({model.model_size()} params), {args.policy_opt.epochs} policy epochs, "
-                               f"global minibatch {mb * world}, Adam, synthetic env (uniform uint8 obs, N(0,1) reward, "
-                               f"p_done 0.01)", "envs_per_gpu": A, "n_steps": N, "global_minibatch": mb * world,
-                   "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-                     # HBM bytes per launch of this kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate
-                     # runs) over this same bench.py command, 2 x FETCH_SIZE + WRITE_SIZE KiB as the guide prescribes
-                     "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": probe_bytes,
-                     "kernel": probe_kernel,
-                     "algorithmic_flops_per_launch": probe_flops, "avg_kernel_ms": round(kern_ms, 4),
-                     "launches_timed": len(probe.events)},
+        "config": {"workload": f"{a.config}: PPO iteration, {A} envs/GPU x {N} steps, obs {tuple(obs_shape)} {obs_kind}, "
+                               f"{n_actions} actions, {net_kind} ({model.model_size()} params), "
+                               f"{args.policy_opt.epochs} policy epochs, global minibatch {mb * world}, Adam, synthetic env",
+                   "envs_per_gpu": A, "n_steps": N, "global_minibatch": mb * world, "parallelism": f"dp{world}"},
+        "roofline": roofline,
         "phase_seconds_per_step": {k: round(v / a.steps, 4) for k, v in phase.items()},
         "model_tflops_whole_step": round(model_tflops / world, 2),
         "model_frac_of_mfma_peak_whole_step": round(model_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
@@ -736,20 +855,46 @@ def main():
         # rollout's recorded launch plans are dropped so that its launches pass through the bracket too)
         nets = list({id(n): n for n in (model.policy_net, model.value_net)}.values())
         for n_ in nets:
-            n_._plans.clear()
-        kt = KernelTable([runner] + nets)
+            n_.use_plans = False
+        kt = KernelTable([runner] + nets, train_batch=mb)
         iteration()
         torch.cuda.synchronize()
         kt.remove()
         for n_ in nets:
-            n_._plans.clear()
-        out["roofline_by_kernel"] = kt.table()
+            n_.use_plans = True
+        table = kt.table()
+        out["roofline_by_kernel"] = table
+        if roofline is not None:
+            # the same kernel at the ROLLOUT's geometry (half-batch env groups: one workgroup per image leaves half the
+            # CUs idle), so that the quoted fraction is not the flattering half of its launches
+            for row in table["rows"]:
+                if row["kernel"].startswith("chained stacks fwd") and "[n=" in row["kernel"] and "frac" in row:
+                    roofline["rollout_geometry"] = {k_: row[k_] for k_ in ("kernel", "launches", "avg_us", "achieved", "frac")}
+                    tr = [r_ for r_ in table["rows"] if r_["kernel"] == row["kernel"].split(" [n=")[0]]
+                    if tr:
+                        n_all = row["launches"] + tr[0]["launches"]
+                        roofline["blended_frac_all_launches"] = round(
+                            (row["frac"] * row["launches"] * row["avg_us"] + tr[0]["frac"] * tr[0]["launches"] * tr[0]["avg_us"])
+                            / (row["launches"] * row["avg_us"] + tr[0]["launches"] * tr[0]["avg_us"]), 4)
+        else:
+            # configs without a hand-picked probe: the table's largest roofline-bound row is the roofline kernel
+            top = next((r_ for r_ in table["rows"] if "frac" in r_), None)
+            if top is not None:
+                out["roofline"] = {"bound": top["bound"], "achieved": top["achieved"],
+                                   "peak": MFMA_F32_PEAK_TFLOPS if top["bound"] == "mfma" else HBM_PEAK_GBPS,
+                                   "unit": top["unit"], "frac": top["frac"], "traffic": None,
+                                   "kernel": top["kernel"] + " (largest roofline-bound share of kernel time, "
+                                             f"{top['share']:.1%}; per-launch HIP events of the extra iteration)",
+                                   "avg_kernel_ms": round(top["avg_us"] * 1e-3, 4), "launches_timed": top["launches"]}
     if rank == 0:
         if world == 1 and not a.no_scan:
             out["gae_scan"] = bench_scan(lib, N, a.scan_envs, A)
             out["tvf_returns"] = bench_tvf(a.tvf_heads)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, A, args.policy_opt.epochs, mb)
+            out["cpu_baseline"] = (cpu_baseline(N, A, args.policy_opt.epochs, mb, tuple(obs_shape), n_actions)
+                                   if a.config != "humanoid_tvf" else
+                                   {"value": None, "note": "the torch-CPU restatement (oracle/model_torch.py) covers the IMPALA "
+                                                           "single-architecture path; not timed for the MLP + TVF config"})
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

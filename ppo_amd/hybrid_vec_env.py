@@ -99,6 +99,49 @@ def _worker(index, env_fns, pipe, raws, obs_shape, obs_dtype, first, total, thre
                 pass
 
 
+class PoolGroup:
+    """A contiguous range of a HybridAsyncVectorEnv's envs (whole workers) as one array-stepping vector env."""
+
+    def __init__(self, pool, index):
+        self.pool, self.index = pool, index
+        first_w, n_w = pool._group_workers(index)
+        self.lo, self.hi = first_w * pool.n_sequential, (first_w + n_w) * pool.n_sequential
+        self.num_envs = self.hi - self.lo
+        self.obs = pool.obs[self.lo:self.hi]
+        self._time = np.zeros(self.num_envs, np.int32)
+        self._len = np.zeros(self.num_envs, np.int32)
+        self._score = np.zeros(self.num_envs, np.float32)
+        self.infos = []
+
+    @property
+    def obs_t(self):
+        import torch
+        return torch.from_numpy(self.obs)
+
+    def step_arrays(self, actions, rew_out=None, done_out=None):
+        """Step the group's envs; rewards / dones are copied into the given rows.  Returns (obs, rew, done) views."""
+        self.pool.step_async(self.index, actions)
+        self.infos = self.pool.step_wait(self.index)
+        rew, done = self.pool._rew[self.lo:self.hi], self.pool._done[self.lo:self.hi]
+        if rew_out is not None:
+            rew_out[:] = rew
+        if done_out is not None:
+            done_out[:] = done
+        for j, info in enumerate(self.infos):  # rl/rollout.py:753, 818-868: time of the landed state, episode stats
+            self._time[j] = info.get("time", 0)
+            self._len[j] = info.get("ep_length", 0)
+            self._score[j] = info.get("ep_score", 0.0)
+        return self.obs, rew, done
+
+    @property
+    def last_episode_stats(self):
+        return self._time, self._len, self._score
+
+    def landed_time(self, done):
+        """Env time of the state each env is now in: what its info dict says (rl/rollout.py:753)."""
+        return self._time
+
+
 class HybridAsyncVectorEnv:
     def __init__(self, env_fns, max_cpus=8, verbose=False, copy=True, allow_threaded=True, context="spawn"):
         assert len(env_fns) % max_cpus == 0, \
@@ -123,6 +166,7 @@ class HybridAsyncVectorEnv:
         self._rew = _as_array(self._raws[1], np.float32, (A,))
         self._done = _as_array(self._raws[2], np.uint8, (A,))
         self._pinned = False
+        self._n_groups = 1
         self.parent_pipes, self.processes = [], []
         for i in range(self.n_parallel):
             parent, child = ctx.Pipe()
@@ -181,6 +225,52 @@ class HybridAsyncVectorEnv:
         per = [list(actions[i * self.n_sequential:(i + 1) * self.n_sequential]) for i in range(self.n_parallel)]
         infos = [info for worker_infos in self._broadcast("step", per) for info in worker_infos]
         return (self.obs.copy() if self.copy else self.obs, self._rew.copy(), self._done.astype(bool), infos)
+
+    # ------------------------------------------------------------------ worker groups (pipelined rollout)
+    def step_async(self, group, actions):
+        """Send `actions` (one per env of the group) to the workers of `group`; returns at once."""
+        first_w, n_w = self._group_workers(group)
+        actions = np.asarray(actions)
+        if len(actions) != n_w * self.n_sequential:
+            raise ValueError(f"group {group} has {n_w * self.n_sequential} envs, got {len(actions)} actions")
+        for w in range(n_w):
+            self.parent_pipes[first_w + w].send(("step", list(actions[w * self.n_sequential:(w + 1) * self.n_sequential])))
+
+    def step_wait(self, group):
+        """Collect the step sent by step_async: observations / rewards / dones are already in the shared block (the
+        workers wrote them in place); returns the per-env info dicts of the group."""
+        first_w, n_w = self._group_workers(group)
+        infos = []
+        for w in range(first_w, first_w + n_w):
+            try:
+                payload, ok = self.parent_pipes[w].recv()
+            except EOFError:
+                raise RuntimeError(f"env worker {w} died during `step`") from None
+            if not ok:
+                self.close(terminate=True)
+                raise RuntimeError(f"env worker {w} failed during `step`:\n{payload}")
+            infos.extend(payload)
+        return infos
+
+    def _group_workers(self, group):
+        per = self.n_parallel // self._n_groups
+        return group * per, per
+
+    def groups(self, count=2):
+        """The pool as `count` independently steppable groups of whole workers (contiguous env ranges), each with the
+        array-stepping interface the Runner's pipelined rollout takes (`step_arrays`, `obs_t`, `last_episode_stats`):
+        the GPU runs one group's policy step while the other group's workers step their envs, and the per-step upload
+        is an async copy out of the group's slice of the pinned block.  [self] when the workers do not divide."""
+        if count < 2 or self.n_parallel % count:
+            count = 1
+        self._n_groups = count
+        return [PoolGroup(self, g) for g in range(count)]
+
+    @property
+    def parts(self):
+        if not hasattr(self, "_parts"):
+            self._parts = self.groups(2)
+        return self._parts
 
     def seed(self, seeds=None):
         seeds = np.reshape(seeds, [self.n_parallel, self.n_sequential])

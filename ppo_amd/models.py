@@ -316,6 +316,7 @@ class DualHeadNet:
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
+        self.use_plans = True  # False: every inference launch goes through _call (bench.py's per-kernel table brackets it)
         self._build_packed_weights()
         self._adam_step = 0
         self.exp_avg = None
@@ -509,7 +510,7 @@ class DualHeadNet:
         # persist, parameters are views of one flat buffer — except the input, which is patched in.  That cuts
         # the per-launch Python work to the ctypes call itself.
         key = (tag, x.shape[0], x.dtype)
-        plan = None if train else self._plans.get(key)
+        plan = None if train or not self.use_plans else self._plans.get(key)
         if plan is not None:
             calls, acts, x_slots = plan
             st, xp = _lib.current_stream(), x.data_ptr()
@@ -522,7 +523,7 @@ class DualHeadNet:
                 for name in plan_input_keys(self.encoder_kind):
                     out[name] = x
             return out
-        if not train:
+        if not train and self.use_plans:
             self._rec = []
         try:
             x_in = x
@@ -539,7 +540,7 @@ class DualHeadNet:
                 hact = self._buf(tag + "hact", tuple(h.shape))
                 self._call("ppo_tanh_forward_f32", _p(h), _p(hact), h.numel())
                 acts["hact"] = hact
-            if not train:
+            if self._rec is not None:
                 xp = x.data_ptr()
                 x_slots = frozenset(k for k, (_f, _n, a) in enumerate(self._rec) if a and a[0] == xp)
                 self._plans[key] = (self._rec, {k: v for k, v in acts.items() if v is not x}, x_slots)

@@ -81,6 +81,7 @@ class Runner:
         self.step = 0
         self.batch_counter = 0
         self.vec_env = None
+        self.force_generic_rollout = False  # tests: the one-group gym-API loop, to compare the pipelined rollout against
         self.N, self.A = args.n_steps, args.agents
         self.state_shape = tuple(model.input_dims)
         self.n_actions = model.actions
@@ -385,9 +386,15 @@ class Runner:
         N, A = self.N, self.A
         self._finished_lengths = [[] for _ in range(N)]
         env = self.vec_env
-        parts = getattr(env, "parts", [env])
-        if all(hasattr(p, "step_arrays") for p in parts):
+        parts = [env] if self.force_generic_rollout else getattr(env, "parts", [env])
+        if not self.force_generic_rollout and all(hasattr(p, "step_arrays") for p in parts):
+            # array-stepping groups: the synthetic env, and gym-API envs behind the process pool and its vector
+            # wrappers (ppo_amd/hybrid_vec_env.py `PoolGroup`, ppo_amd/wrappers.py `parts`)
             self._rollout_pipelined(parts)
+            if hasattr(env, "finish_rollout"):
+                # what the vector wrappers do to the rewards needs every env's reward of a step at once (the running
+                # return statistics): applied here, step by step in the reference's order, once the rollout is in
+                env.finish_rollout(self._rewards_host.numpy(), self._dones_host.numpy())
         else:
             self._rollout_generic(env)
         self.ext_rewards.copy_(self._rewards_host, non_blocking=True)
@@ -449,7 +456,7 @@ class Runner:
             parts[i].step_arrays(act_np[lo:hi], rew_np[t, lo:hi], done_np[t, lo:hi])
             time_now, ep_len, ep_score = parts[i].last_episode_stats
             done = done_np[t, lo:hi].astype(bool)
-            self.all_time[t + 1, lo:hi] = np.where(done, 0, time_now)  # a finished env shows the first state of a new episode
+            self.all_time[t + 1, lo:hi] = parts[i].landed_time(done)
             self._log_finished(done, ep_len, ep_score, t)
 
         tags = [f"i{i}" if P > 1 else "i" for i in range(P)]
@@ -525,7 +532,9 @@ class Runner:
         stream = torch.cuda.current_stream()
         for t in range(N + 1):
             self.all_time[t] = self.time
-            self.all_obs[t].copy_(torch.from_numpy(np.ascontiguousarray(self.obs)), non_blocking=True)
+            # zero-copy view: with the process pool self.obs IS the shared pinned block, so this is one async H2D
+            src = self.obs if self.obs.flags.c_contiguous else np.ascontiguousarray(self.obs)
+            self.all_obs[t].copy_(torch.from_numpy(src), non_blocking=True)
             if norm is not None and t < N:
                 norm.update(self.all_obs[t])
             self._policy_step(t)

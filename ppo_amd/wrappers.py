@@ -30,6 +30,33 @@ class VecWrapper:
         return self.env.close()
 
 
+class _Part:
+    """One array-stepping group of a wrapped vector env (the Runner's pipelined rollout steps groups, not the whole
+    env): forwards to the inner env's group; a wrapper's own per-group work goes into `after_step`."""
+
+    def __init__(self, wrapper, inner, lo):
+        self.wrapper, self.inner, self.lo = wrapper, inner, lo
+        self.hi = lo + inner.num_envs
+        self.num_envs = inner.num_envs
+
+    def __getattr__(self, name):
+        if name == "inner":
+            raise AttributeError(name)
+        return getattr(self.inner, name)
+
+    def step_arrays(self, actions, rew_out=None, done_out=None):
+        out = self.inner.step_arrays(actions, rew_out, done_out)
+        self.wrapper._after_group_step(self, actions)
+        return out
+
+
+def _inner_parts(env):
+    parts = getattr(env, "parts", None)
+    if parts is None or not all(hasattr(p, "step_arrays") for p in parts):
+        return None
+    return parts
+
+
 def get_wrapper(env, wrapper_type):
     """Walk the `.env` chain for the first wrapper of the given type (rl/wrappers.py `get_wrapper`)."""
     while env is not None:
@@ -67,6 +94,39 @@ class VecRepeatedActionPenalty(VecWrapper):
             infos[i]["repeated_action"] = actions[i]
         self.prev_actions[:] = actions
         return obs, rewards - (over * self.penalty), dones, infos
+
+    # ---- group-wise stepping: the counters are per env, so a group updates its own slice; the penalties of a rollout
+    # are kept and subtracted in finish_rollout, AFTER the inner wrappers have had the rewards (the reference's order:
+    # the penalty comes off the normalised reward)
+    @property
+    def parts(self):
+        if "_parts" not in self.__dict__:
+            inner = _inner_parts(self.env)
+            lo, parts = 0, []
+            for q in inner or []:
+                parts.append(_Part(self, q, lo))
+                lo += q.num_envs
+            self._parts = parts if inner else [self]
+            self._penalties = [[] for _ in parts]
+        return self._parts
+
+    def _after_group_step(self, part, actions):
+        actions = np.asarray(actions)
+        sl = slice(part.lo, part.hi)
+        repeated = (actions == self.prev_actions[sl]) & (actions >= 0)
+        self.duplicate_counter[sl] = (self.duplicate_counter[sl] + repeated) * repeated
+        over = self.duplicate_counter[sl] > self.max_repeated_actions
+        self.prev_actions[sl] = actions
+        self._penalties[self._parts.index(part)].append(over * self.penalty)
+
+    def finish_rollout(self, rewards, dones):
+        """rewards / dones [N, A] of the rollout just stepped group by group, in place."""
+        if hasattr(self.env, "finish_rollout"):
+            self.env.finish_rollout(rewards, dones)
+        for part, rows in zip(self._parts, self._penalties):
+            if rows:
+                rewards[:len(rows), part.lo:part.hi] -= np.stack(rows).astype(rewards.dtype)
+            rows.clear()
 
 
 class VecNormalizeRewardWrapper(VecWrapper):
@@ -133,6 +193,35 @@ class VecNormalizeRewardWrapper(VecWrapper):
                 infos[0]["reward_clips"] = n_clipped
             out = bounded
         return obs, out * self.scale, dones, infos
+
+    # ---- group-wise stepping: the statistics of step t take in EVERY env's return of step t before any reward of that
+    # step is scaled, so the groups only record; finish_rollout replays the rollout step by step - the same arithmetic
+    # on the same arrays as `step`, hence the same bits
+    @property
+    def parts(self):
+        if "_parts" not in self.__dict__:
+            inner = _inner_parts(self.env)
+            lo, parts = 0, []
+            for q in inner or []:
+                parts.append(_Part(self, q, lo))
+                lo += q.num_envs
+            self._parts = parts if inner else [self]
+        return self._parts
+
+    def _after_group_step(self, part, actions):
+        pass
+
+    def finish_rollout(self, rewards, dones):
+        """rewards / dones [N, A] of the rollout just stepped group by group: normalised in place."""
+        if hasattr(self.env, "finish_rollout"):
+            self.env.finish_rollout(rewards, dones)
+        for t in range(rewards.shape[0]):
+            raw = rewards[t].copy()
+            self._track(raw, dones[t].astype(bool))
+            out = raw / self.std
+            if self.clip is not None and self.clip >= 0:
+                out = np.clip(out, -self.clip, +self.clip)
+            rewards[t] = out * self.scale
 
     @property
     def mean(self):

@@ -442,3 +442,73 @@ class Recorder:
 
     def watch_mean(self, key, value, **kw):
         self.got[key] = float(value)
+
+
+def _rollout_buffers(r):
+    torch.cuda.synchronize()
+    return {k: getattr(r, k).clone() for k in ("all_obs", "actions", "ext_rewards", "terminals", "value", "log_pac",
+                                               "raw_policy")} | {"all_time": torch.from_numpy(r.all_time.copy())}
+
+
+@pytest.mark.parametrize("stack", ["cartpole_pool", "atari_stack"])
+def test_pipelined_rollout_of_gym_api_envs_fills_the_same_buffers_as_the_one_group_loop(stack):
+    """north_star: "vectorised envs ... via rl.hybridVecEnv step on host cores with pinned async obs copies".  gym-API envs
+    behind the process pool (two worker groups) and the vector wrappers (rms reward normalisation, repeated-action
+    penalty) take the Runner's group-pipelined rollout - one group's workers step while the GPU runs the other group's
+    policy, uploads are async copies out of the pinned block, the only host wait is the group's own action event - and
+    must fill the rollout buffers with the very bytes of the plain forward -> sync -> step loop (rl/rollout.py:730-752),
+    over two rollouts (normaliser statistics and penalty counters carry over)."""
+    import functools
+
+    def build():
+        if stack == "cartpole_pool":
+            args.setup(["--agents=16", "--n_steps=24", "--model_architecture=single", "--model_encoder=mlp",
+                        "--model_hidden_units=64", "--env_type=classic", "--env_name=CartPole", "--seed=2", "--device=cuda",
+                        "--policy_opt_mini_batch_size=128", "--workers=4", "--gamma=0.99", "--disable_logging=True",
+                        "--env_max_repeated_actions=3", "--env_repeated_action_penalty=0.25"])
+            torch.manual_seed(2)
+            np.random.seed(2)
+            model = models.TVFModel("mlp", input_dims=(4,), actions=2, device="cuda", architecture="single",
+                                    hidden_units=64, head_scale=0.1, head_bias=True)
+            r = rollout.Runner(model, logger.Logger(quiet=True))
+            r.vec_env = envs.create_envs_classic()
+        else:
+            args.setup(["--agents=8", "--n_steps=24", "--model_architecture=single", "--model_encoder=impala",
+                        "--env_type=atari", "--env_name=FakeGame", "--env_timeout=40", "--env_noop_duration=4", "--seed=5",
+                        "--device=cuda", "--policy_opt_mini_batch_size=64", "--workers=8", "--disable_logging=True"])
+            # one env per worker: the wrappers draw from the worker's global np.random (as the reference's do), and two
+            # envs of one worker step on two threads - their draw order is a race in either rollout form
+            torch.manual_seed(5)
+            np.random.seed(5)
+            shape, nA = envs.get_env_spec()
+            model = models.TVFModel("impala", input_dims=shape, actions=nA, device="cuda", architecture="single",
+                                    hidden_units=256, head_scale=0.1, head_bias=True)
+            r = rollout.Runner(model, logger.Logger(quiet=True))
+            r.vec_env = envs.create_envs_classic(
+                env_fns=[functools.partial(_fake_atari_env, 100 + 997 * i, args) for i in range(8)])
+        return r
+
+    runs = {}
+    for mode in ("generic", "pipelined"):
+        r = build()
+        try:
+            from ppo_amd import wrappers
+            r.force_generic_rollout = mode == "generic"
+            parts = getattr(r.vec_env, "parts", [r.vec_env])
+            assert len(parts) == 2 and all(hasattr(p, "step_arrays") for p in parts), "the stack must offer two groups"
+            assert wrappers.get_wrapper(r.vec_env, wrappers.VecNormalizeRewardWrapper) is not None
+            r.reset()
+            bufs = []
+            for _ in range(2):
+                r.generate_rollout()
+                bufs.append(_rollout_buffers(r))
+            norm = wrappers.get_wrapper(r.vec_env, wrappers.VecNormalizeRewardWrapper)
+            runs[mode] = (bufs, float(norm.ret_rms.var), norm.current_returns.copy(), r.time.copy(), r.ep_count)
+        finally:
+            r.vec_env.close()
+    (ga, gvar, gret, gtime, gep), (pa, pvar, pret, ptime, pep) = runs["generic"], runs["pipelined"]
+    for it in range(2):
+        for k in ga[it]:
+            assert torch.equal(ga[it][k], pa[it][k]), (it, k)
+    assert gvar == pvar and np.array_equal(gret, pret) and np.array_equal(gtime, ptime) and gep == pep
+    assert int(ga[1]["terminals"].sum()) > 0 and float(ga[1]["ext_rewards"].abs().sum()) > 0

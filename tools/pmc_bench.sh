@@ -17,6 +17,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   r=$?; echo "$C pass exit $r"; tail -3 $OUT/$c.log
   [ $r -ne 0 ] && rc=$r && break
 done
+# which kernel sources the counters belong to: bench.py reports the traffic only while they are unchanged
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.kernel_source_hash())" > $OUT/kernel_source_sha16.txt
 find $OUT -name "*.db" -delete
 find $OUT -name "*counter_collection.csv" | head
 exit $rc

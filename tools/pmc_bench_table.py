@@ -38,7 +38,9 @@ for key in sorted(set(fetch) & set(write)):
 rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
 how = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --n-steps 8 --steps 1 --warmup 1` (tools/pmc_bench.sh: the bench iteration with a short rollout, every training kernel at its minibatch geometry), "
        "average over the training-minibatch launches, (2 x FETCH + WRITE) KiB")
-out = {"tag": tag, "rows": rows[:60]}
+sha_file = os.path.join(src, "kernel_source_sha16.txt")
+out = {"tag": tag, "kernel_source_sha16": open(sha_file).read().strip() if os.path.exists(sha_file) else None,
+       "rows": rows[:60]}
 for short in ("stack_full_kernel", "stack_tail_kernel", "conv3x3_kernel"):
     cand = [r for r in rows if r["kernel"].startswith(short)]
     if cand:
