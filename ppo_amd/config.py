@@ -104,10 +104,11 @@ class EnvConfig(_Group):  # rl/config.py:495-603
         ("procgen_difficulty", str, "hard", "[hard|easy] (:533)"),
         ("zero_obs", bool, False, "blank observations (the reference's --debug_zero_obs)"),
         ("synthetic_done_prob", float, 0.01, "synthetic env: per-step termination probability"),
-        ("synthetic_threads", int, 8, "synthetic env: host threads generating observations"),
+        ("synthetic_threads", int, 16, "synthetic env: host threads generating observations (a GPU's share of the host cores)"),
         ("synthetic_actions", int, 0, "synthetic env: size of the action set (0 = 6, the Pong-shaped default)"),
         ("synthetic_shape", str, None, "synthetic env: observation shape 'C,H,W' (default 4,84,84; procgen-shaped: 3,64,64)"),
         ("pipeline_parts", int, 2, "split the envs into this many groups so host stepping overlaps the GPU policy step"),
+        ("pipeline_leaves", int, 1, "step and upload each group in this many pieces, a piece's upload running while the next is stepped (measured: 0.494 / 0.558 / 0.792 ms per env step for 1 / 2 / 4 - a thread-pool dispatch per piece costs more than the overlap returns)"),
     )
 
 

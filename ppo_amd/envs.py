@@ -12,7 +12,7 @@ import numpy as np
 
 from . import parallel
 from .config import args
-from .vec_env import SplitVecEnv, SyntheticVecEnv
+from .vec_env import EnvGroup, SplitVecEnv, SyntheticVecEnv
 
 OBS_SHAPES = {"atari": (4, 84, 84), "procgen": (3, 64, 64), "synthetic": (4, 84, 84), "classic": (4,)}
 
@@ -121,5 +121,10 @@ def create_envs_classic(N=None, rank=0, world=1, env_fns=None, monitor_video=Fal
     if parts > 1 and N % parts == 0 and N // parts >= 16:
         # env streams are keyed by the GLOBAL env index, so the split changes nothing but the overlap
         per = N // parts
+        leaves = int(args.env.pipeline_leaves)
+        if leaves > 1 and per % leaves == 0 and per // leaves >= 16:
+            sub = per // leaves
+            return SplitVecEnv([EnvGroup([make(sub, rank * N + i * per + k * sub) for k in range(leaves)])
+                                for i in range(parts)])
         return SplitVecEnv([make(per, rank * N + i * per) for i in range(parts)])
     return make(N, rank * N)

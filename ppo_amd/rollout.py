@@ -427,21 +427,36 @@ class Runner:
             if s_ is not main:
                 s_.wait_stream(main)
         graphs = [self._rollout_graph(i, bounds[i + 1] - bounds[i], streams[i]) if P > 1 else None for i in range(P)]
+        norm = self.model.obs_norm
+
+        # a group may be stepped (and uploaded) in several pieces: a leaf's H2D runs while the next leaf is stepped
+        leaves = []
+        for i in range(P):
+            lo, row = bounds[i], []
+            for leaf in getattr(parts[i], "leaves", [parts[i]]):
+                row.append((leaf, lo, lo + leaf.num_envs))
+                lo += leaf.num_envs
+            leaves.append(row)
+
+        def upload(i, t, only=None):
+            # H2D of group i's observations (pinned -> HBM) into row t on the copy stream, so it runs on a DMA engine
+            # under the other group's policy step.  (set_stream rather than the `with torch.cuda.stream` context: this
+            # runs 2 x 257 times per rollout and the host is on the critical path; the caller restores the stream)
+            torch.cuda.set_stream(copy_stream)
+            for leaf, lo, hi in (leaves[i] if only is None else [only]):
+                if graphs[i] is not None:  # the graph reads a fixed staging buffer; the rollout row is a D2D copy of it
+                    graphs[i][1][lo - bounds[i]:hi - bounds[i]].copy_(leaf.obs_t, non_blocking=True)
+                else:
+                    self.all_obs[t, lo:hi].copy_(leaf.obs_t, non_blocking=True)
 
         def enqueue(i, t):
-            # H2D of group i's observations (pinned -> HBM) on the copy stream, so it runs on a DMA engine
-            # under the other group's policy step; then policy + sampling, actions D2H; all async
+            # policy + sampling for group i at step t behind its upload (issued when its envs were stepped), actions D2H;
+            # all async
             lo, hi = bounds[i], bounds[i + 1]
-            # (set_stream rather than the `with torch.cuda.stream` context: this runs 2 x 257 times per rollout
-            # and the host is on the critical path; the main stream is restored in the finally below)
-            torch.cuda.set_stream(copy_stream)
-            if graphs[i] is not None:  # the graph reads a fixed staging buffer; the rollout row is a D2D copy of it
-                graphs[i][1].copy_(parts[i].obs_t, non_blocking=True)
+            if graphs[i] is not None:
+                torch.cuda.set_stream(copy_stream)
                 copy_events[i].record()
                 self.all_obs[t, lo:hi].copy_(graphs[i][1], non_blocking=True)
-            else:
-                self.all_obs[t, lo:hi].copy_(parts[i].obs_t, non_blocking=True)
-                copy_events[i].record()
             torch.cuda.set_stream(streams[i])
             streams[i].wait_event(copy_events[i])
             self._policy_step(t, lo, hi, tag=tags[i], graph=graphs[i])
@@ -450,10 +465,16 @@ class Runner:
                 events[i].record()
 
         def step_envs(i, t):
-            # the one host wait of group i's step: its actions have landed; then step it on host cores
-            lo, hi = bounds[i], bounds[i + 1]
+            # the one host wait of group i's step: its actions have landed; then step it on host cores, leaf by leaf,
+            # each leaf's next observations going up as soon as they exist
             events[i].synchronize()
-            parts[i].step_arrays(act_np[lo:hi], rew_np[t, lo:hi], done_np[t, lo:hi])
+            for leaf, lo, hi in leaves[i]:
+                leaf.step_arrays(act_np[lo:hi], rew_np[t, lo:hi], done_np[t, lo:hi])
+                if norm is None:
+                    upload(i, t + 1, only=(leaf, lo, hi))
+            if norm is None:
+                copy_events[i].record()  # (current stream = the copy stream: upload() left it so)
+            lo, hi = bounds[i], bounds[i + 1]
             time_now, ep_len, ep_score = parts[i].last_episode_stats
             done = done_np[t, lo:hi].astype(bool)
             self.all_time[t + 1, lo:hi] = parts[i].landed_time(done)
@@ -461,7 +482,6 @@ class Runner:
 
         tags = [f"i{i}" if P > 1 else "i" for i in range(P)]
         host_rows = [self._actions_host[bounds[i]:bounds[i + 1]] for i in range(P)]
-        norm = self.model.obs_norm
         if norm is not None:
             # Observation normalisation: the running statistics take in EVERY env's observation of step t before any
             # group's forward of step t (rl/rollout.py:735-741), so the groups cannot run a step apart.  Per step: both
@@ -472,9 +492,8 @@ class Runner:
                 self._norm_event = torch.cuda.Event()
             try:
                 for t in range(N + 1):
-                    torch.cuda.set_stream(copy_stream)
                     for i in range(P):
-                        self.all_obs[t, bounds[i]:bounds[i + 1]].copy_(parts[i].obs_t, non_blocking=True)
+                        upload(i, t)
                     copy_events[0].record()
                     torch.cuda.set_stream(streams[0])
                     streams[0].wait_event(copy_events[0])
@@ -505,6 +524,9 @@ class Runner:
             self.obs = parts[0].obs if P == 1 else np.concatenate([p.obs for p in parts])
             return
         try:
+            for i in range(P):  # the observations the envs hold now are row 0; later rows go up from step_envs
+                upload(i, 0)
+                copy_events[i].record()
             for t in range(N + 1):
                 for i in range(P):
                     enqueue(i, t)  # needs obs(i, t): group i was stepped for t-1 below
