@@ -47,7 +47,7 @@ SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write 
 FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
 # HBM bytes per launch of the roofline kernel from rocprofv3 --pmc passes over THIS command (tools/pmc_bench.sh
 # -> profiles/<tag>_bench_hbm_traffic.json); absent file => traffic null
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_bench_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "bench_hbm_traffic.json")  # the latest pass (tools/round_artifacts.py)
 
 
 # BASELINE.json `configs`, as synthetic workloads of the named shape (synthetic rollouts; the simulators

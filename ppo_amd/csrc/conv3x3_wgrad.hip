@@ -57,6 +57,21 @@ constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : PPO_
 template <int IN_MODE, bool DY_POOLED>
 constexpr bool wgrad_run() { return true; }  // (the halo-column layout remains for reference behind RUN = false)
 constexpr int kWgradWaves = 8;
+// A ninth wave that does nothing but issue the NEXT item's LDS-DMA while the eight compute waves run this item's K loop.
+// Stamps of the 16 -> 16 42x42 layer (one resident workgroup per CU, 12 k cycles per item): K loop 60 %, item barrier
+// 23 %, DMA issue 13 % - every compute wave stopped feeding the MFMA pipe to issue its share of ~100 requests, all of
+// them at the same time, and the skew of that issue phase came back as barrier wait.  Only where both bands arrive by
+// DMA into a second buffer (not the uint8 first layer, not the pooled-gradient gather, not one-item workgroups).
+#ifndef PPO_TUNE_WGRAD_DMA_WAVE
+#define PPO_TUNE_WGRAD_DMA_WAVE 1
+#endif
+template <int IN_MODE, int NBANDS, bool DY_POOLED>
+constexpr bool wgrad_dma_wave()
+{
+    return PPO_TUNE_WGRAD_DMA_WAVE && wgrad_nbuf<IN_MODE, NBANDS>() == 2 && IN_MODE != IN_U8 && !DY_POOLED;
+}
+template <int IN_MODE, int NBANDS, bool DY_POOLED>
+constexpr int wgrad_threads() { return (kWgradWaves + (wgrad_dma_wave<IN_MODE, NBANDS, DY_POOLED>() ? 1 : 0)) * 64; }
 
 template <int CIN, int COUT, int H, int W, int TR, int NBUF_, bool RUN_>
 struct WgradCfg {
@@ -189,9 +204,11 @@ struct WgradBatch {
 };
 
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE, bool DY_POOLED = false>
-__global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBatch batch, int n_images)
+__global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLED>())) void conv3x3_wgrad_kernel(WgradBatch batch,
+                                                                                                                int n_images)
 {
     using C = WgradCfg<CIN, COUT, H, W, TR, wgrad_nbuf<IN_MODE, (H + TR - 1) / TR>(), wgrad_run<IN_MODE, DY_POOLED>()>;
+    constexpr bool DMAW = wgrad_dma_wave<IN_MODE, (H + TR - 1) / TR, DY_POOLED>();
     const void *__restrict__ in_ = batch.in[blockIdx.y];
     const float *__restrict__ dy = batch.dy[blockIdx.y];
     float *__restrict__ partial = batch.partial[blockIdx.y];
@@ -203,6 +220,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
     const int lane = tid & 63;
     PPO_STAMP(t_k0)
     const int wave = tid >> 6;
+    const bool is_dma = DMAW && wave == kWgradWaves;  // the staging wave: no tiles, no K group (kg below is out of range)
     const int wt = wave % C::WT;  // owner of N tiles wt, wt + WT, ...
     const int kg = wave / C::WT;  // K-split group
     const int l15 = lane & 15;
@@ -236,13 +254,15 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 
     // zero everything once (halo columns, padded channels and padded dy columns are never written by the
     // LDS-DMA staging), then the constant planes
-    zero_lds<C::NBUF * C::LDS_BUF, kWgradWaves * 64>(smem, tid);
+    if (!is_dma) zero_lds<C::NBUF * C::LDS_BUF, kWgradWaves * 64>(smem, tid);
     __syncthreads();
     if constexpr (C::BIAS_IN_TILE)
         for (int b = 0; b < C::NBUF; ++b)
-            for (int i = tid; i < C::XPLANE; i += kWgradWaves * 64) s_x[b * C::LDS_BUF + C::CINP * C::XPLANE + i] = 1.0f;
+            for (int i = tid; i < C::XPLANE && !is_dma; i += kWgradWaves * 64) s_x[b * C::LDS_BUF + C::CINP * C::XPLANE + i] = 1.0f;
 
     const int n_items = n_images * C::NBANDS;
+    constexpr int SW = DMAW ? 1 : kWgradWaves;  // waves that share the staging of an item
+    const int stid = DMAW ? lane : tid;
     auto stage = [&](int item, float *bx, float *bd) {
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
@@ -253,14 +273,14 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
                 band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, img, y0, tid, raw);
                 band_u8x4_store<CIN, W, C::ROWS, C::XPLANE, C::G, kWgradWaves * 64>(raw, bx, tid);
             } else {
-                stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, kWgradWaves>(static_cast<const float *>(in_), img, y0, bx, tid);
+                stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, SW>(static_cast<const float *>(in_), img, y0, bx, stid);
             }
             if constexpr (DY_POOLED) {
                 static_assert(C::LDS_X % 2 == 0 && C::LDS_BUF % 2 == 0 && C::DPLANE % 2 == 0, "stage_dy_pooled stores float2 pairs");
                 stage_dy_pooled<COUT, H, W, TR, C::PWD, C::DPLANE, kWgradWaves>(dy, batch.argmax, img, y0, bd, tid);
             } else {
                 // the same routine for the TR rows y0 .. y0 + TR - 1 of dy: its first row is (y0 + 1) - 1, no guard
-                stage_band_chunk_dma<COUT, H, W, TR, C::DPLANE, 0, kWgradWaves>(dy, img, y0 + 1, bd, tid);
+                stage_band_chunk_dma<COUT, H, W, TR, C::DPLANE, 0, SW>(dy, img, y0 + 1, bd, stid);
             }
             return;
         } else if constexpr (IN_MODE == IN_U8)
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
     PPO_STAMP_ADD(6, t_k1, t_k0)  // prologue: lane constants, LDS zeroing
     if constexpr (C::NBUF == 2) {
         int buf = 0;
-        if ((int)blockIdx.x < n_items) stage(blockIdx.x, s_x, s_d);
+        if ((int)blockIdx.x < n_items && (!DMAW || is_dma)) stage(blockIdx.x, s_x, s_d);
         for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
             const float *bx = s_x + buf * C::LDS_BUF, *bd = s_d + buf * C::LDS_BUF;
             PPO_STAMP(t_top)
@@ -291,10 +311,10 @@ __global__ __launch_bounds__(kWgradWaves * 64) void conv3x3_wgrad_kernel(WgradBa
 #endif
             __syncthreads();  // this item's bands have landed (vmcnt(0)); every wave is done with the other buffer
             PPO_STAMP(t_bar)
-            if (item + (int)gridDim.x < n_items)
+            if (item + (int)gridDim.x < n_items && (!DMAW || is_dma))
                 stage(item + gridDim.x, s_x + (buf ^ 1) * C::LDS_BUF, s_d + (buf ^ 1) * C::LDS_BUF);
             PPO_STAMP(t_staged)
-            wgrad_k_loops<C, RELU>(bx, bd, joff, ml, mr, aoff, g, wt, kg, acc, asum);
+            if (!is_dma) wgrad_k_loops<C, RELU>(bx, bd, joff, ml, mr, aoff, g, wt, kg, acc, asum);
             PPO_STAMP(t_end)
             PPO_STAMP_ADD(0, t_bar, t_top)      // barrier wait
             PPO_STAMP_ADD(1, t_staged, t_bar)   // DMA issue of the next item
@@ -588,7 +608,8 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
         batch.partial[0] = workspace;
     }
     batch.argmax = argmax;
-    hipLaunchKernelGGL(kern, dim3(grid, count), dim3(kWgradWaves * 64), C::LDS_BYTES, st, batch, n_images);
+    hipLaunchKernelGGL(kern, dim3(grid, count), dim3(wgrad_threads<IN_MODE, C::NBANDS, DY_POOLED>()), C::LDS_BYTES, st, batch,
+                       n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
     if (rc) return rc;
     if (n_slabs_out) {  // slabs only: the caller reduces later (ppo_conv3x3_wgrad_reduce_f32)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn one verification run (tools/profile_bench.sh <tag>, tools/pmc_bench.sh <tag>, bench.py > gpurun_out/bench_<tag>.log)
 into the tracked files under profiles/: kernel stats + top kernels + summary (summarize_profile.py), HBM traffic table
-(pmc_bench_table.py, also copied to profiles/r02_bench_hbm_traffic.* which bench.py reads), the bench line and the
+(pmc_bench_table.py, also copied to profiles/bench_hbm_traffic.* which bench.py reads), the bench line and the
 per-kernel roofline table.  Usage: python tools/round_artifacts.py <tag>"""
 import json
 import os
@@ -14,8 +14,10 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 subprocess.run([sys.executable, os.path.join(root, "tools", "summarize_profile.py"), tag], check=True, stdout=subprocess.DEVNULL)
 subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_bench_table.py"), tag], check=True, stdout=subprocess.DEVNULL)
+if os.path.isdir(os.path.join(root, "gpurun_out", f"pmct_{tag}")):
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_tvf_table.py"), tag], check=True, stdout=subprocess.DEVNULL)
 for ext in ("json", "md"):
-    shutil.copy(os.path.join(prof, f"{tag}_bench_hbm_traffic.{ext}"), os.path.join(prof, f"r02_bench_hbm_traffic.{ext}"))
+    shutil.copy(os.path.join(prof, f"{tag}_bench_hbm_traffic.{ext}"), os.path.join(prof, f"bench_hbm_traffic.{ext}"))
 line = [l for l in open(os.path.join(root, "gpurun_out", f"bench_{tag}.log")) if l.startswith("{")][-1]
 d = json.loads(line)
 json.dump(d, open(os.path.join(prof, f"{tag}_bench_line.json"), "w"), indent=1)
