@@ -57,21 +57,25 @@ constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : PPO_
 template <int IN_MODE, bool DY_POOLED>
 constexpr bool wgrad_run() { return true; }  // (the halo-column layout remains for reference behind RUN = false)
 constexpr int kWgradWaves = 8;
-// A ninth wave that does nothing but issue the NEXT item's LDS-DMA while the eight compute waves run this item's K loop.
-// Stamps of the 16 -> 16 42x42 layer (one resident workgroup per CU, 12 k cycles per item): K loop 60 %, item barrier
-// 23 %, DMA issue 13 % - every compute wave stopped feeding the MFMA pipe to issue its share of ~100 requests, all of
-// them at the same time, and the skew of that issue phase came back as barrier wait.  Only where both bands arrive by
-// DMA into a second buffer (not the uint8 first layer, not the pooled-gradient gather, not one-item workgroups).
+// Four extra waves (one per SIMD) that do nothing but issue the NEXT item's LDS-DMA while the eight compute waves run
+// this item's K loop.  Stamps of the 16 -> 16 42x42 layer (one resident workgroup per CU, 12 k cycles per item): K loop
+// 60 %, item barrier 23 %, DMA issue 13 % - every compute wave stopped feeding the MFMA pipe to issue its share of ~100
+// requests, all of them at the same time, and the skew of that issue phase came back as barrier wait.  Measured on the
+// whole training step (tools/model_speed.py, batch 256): 0 staging waves 1.112 ms, 1 -> 1.178 (one wave cannot issue an
+// item's requests within a K loop: the compute waves wait for IT), 2 -> 1.113, 4 -> 1.089, 8 -> 1.123.  Only where both
+// bands arrive by DMA into a second buffer (not the uint8 first layer, not the pooled-gradient gather, not one-item
+// workgroups).
 #ifndef PPO_TUNE_WGRAD_DMA_WAVE
-#define PPO_TUNE_WGRAD_DMA_WAVE 1
+#define PPO_TUNE_WGRAD_DMA_WAVE 4
 #endif
 template <int IN_MODE, int NBANDS, bool DY_POOLED>
 constexpr bool wgrad_dma_wave()
 {
     return PPO_TUNE_WGRAD_DMA_WAVE && wgrad_nbuf<IN_MODE, NBANDS>() == 2 && IN_MODE != IN_U8 && !DY_POOLED;
 }
+constexpr int kWgradDmaWaves = PPO_TUNE_WGRAD_DMA_WAVE;  // staging waves (0 = the compute waves stage)
 template <int IN_MODE, int NBANDS, bool DY_POOLED>
-constexpr int wgrad_threads() { return (kWgradWaves + (wgrad_dma_wave<IN_MODE, NBANDS, DY_POOLED>() ? 1 : 0)) * 64; }
+constexpr int wgrad_threads() { return (kWgradWaves + (wgrad_dma_wave<IN_MODE, NBANDS, DY_POOLED>() ? kWgradDmaWaves : 0)) * 64; }
 
 template <int CIN, int COUT, int H, int W, int TR, int NBUF_, bool RUN_>
 struct WgradCfg {
@@ -220,9 +224,9 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
     const int lane = tid & 63;
     PPO_STAMP(t_k0)
     const int wave = tid >> 6;
-    const bool is_dma = DMAW && wave == kWgradWaves;  // the staging wave: no tiles, no K group (kg below is out of range)
+    const bool is_dma = DMAW && wave >= kWgradWaves;  // a staging wave: no tiles, no K group
     const int wt = wave % C::WT;  // owner of N tiles wt, wt + WT, ...
-    const int kg = wave / C::WT;  // K-split group
+    const int kg = is_dma ? -1 : wave / C::WT;  // K-split group
     const int l15 = lane & 15;
     const int g = lane >> 4;
 
@@ -261,8 +265,8 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
             for (int i = tid; i < C::XPLANE && !is_dma; i += kWgradWaves * 64) s_x[b * C::LDS_BUF + C::CINP * C::XPLANE + i] = 1.0f;
 
     const int n_items = n_images * C::NBANDS;
-    constexpr int SW = DMAW ? 1 : kWgradWaves;  // waves that share the staging of an item
-    const int stid = DMAW ? lane : tid;
+    constexpr int SW = DMAW ? kWgradDmaWaves : kWgradWaves;  // waves that share the staging of an item
+    const int stid = DMAW ? tid - kWgradWaves * 64 : tid;
     auto stage = [&](int item, float *bx, float *bd) {
         const int img = item / C::NBANDS;
         const int y0 = (item % C::NBANDS) * TR;
