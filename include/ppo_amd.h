@@ -347,6 +347,14 @@ size_t ppo_adam_workspace_bytes(void);
 int ppo_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
                       double lr, double beta1, double beta2, double eps, float max_grad_norm, float grad_div,
                       void *workspace, float *grad_norm_out, void *stream);
+/* The same step that also writes every updated parameter j < n_scatter to packed[scatter[2j]] and packed[scatter[2j+1]]
+ * (-1 = nowhere): the head of the flat buffer holds the convolution weights, and their pre-packed MFMA operand layouts
+ * (ppo_conv3x3_pack_weights_f32: forward, and flipped / transposed for backward-data) are refreshed by the optimiser
+ * step itself instead of by a launch of their own before the next forward (rl/rollout.py:1319 optimizer.step()). */
+int ppo_adam_step_scatter_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
+                              double lr, double beta1, double beta2, double eps, float max_grad_norm, float grad_div,
+                              void *workspace, float *grad_norm_out, const int32_t *scatter, int64_t n_scatter,
+                              float *packed, void *stream);
 
 /*
  * dst[r, :] = src[index[r], :] for r < n_rows; rows are row_bytes bytes (minibatch gather of

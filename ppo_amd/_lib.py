@@ -90,6 +90,7 @@ SIGNATURES = {
     "ppo_obs_normalize_f32": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
+    "ppo_adam_step_scatter_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
 }
 
 class PackJob(ctypes.Structure):

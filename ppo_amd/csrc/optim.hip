@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
                                                    float one_minus_beta1, float beta2, float one_minus_beta2,
                                                    float eps, float bias_c1,
                                                    float bias_c2_sqrt, float max_norm, float grad_div,
-                                                   float *__restrict__ norm_out)
+                                                   float *__restrict__ norm_out, const int32_t *__restrict__ scatter,
+                                                   int64_t n_scatter, float *__restrict__ packed)
 {
     __shared__ float s_clip;
     __shared__ float s_part[256];
@@ -100,6 +101,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
             w4[i] = ww;
             m4[i] = mm;
             v4[i] = vv;
+            if (4 * i < n_scatter) {
+                // the head of the flat buffer holds the convolution weights: their updated values also go to where the
+                // convolution kernels read them, the per-lane MFMA operand layouts (forward and flipped / transposed),
+                // so no re-pack launch sits between this step and the next forward
+                const float nw[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t j = 4 * i + e;
+                    if (j < n_scatter) {
+                        const int d0 = scatter[2 * j], d1 = scatter[2 * j + 1];
+                        if (d0 >= 0) packed[d0] = nw[e];
+                        if (d1 >= 0) packed[d1] = nw[e];
+                    }
+                }
+            }
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -108,6 +124,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
             w[i] = wi;
             m[i] = mi;
             v[i] = vi;
+            if (i < n_scatter) {
+                const int d0 = scatter[2 * i], d1 = scatter[2 * i + 1];
+                if (d0 >= 0) packed[d0] = wi;
+                if (d1 >= 0) packed[d1] = wi;
+            }
         }
     }
 }
@@ -117,9 +138,32 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
 
 extern "C" size_t ppo_adam_workspace_bytes(void) { return ppo::kPartials * sizeof(float); }
 
+static int adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, double lr,
+                     double beta1, double beta2, double eps, float max_grad_norm, float grad_div, void *workspace,
+                     float *grad_norm_out, const int32_t *scatter, int64_t n_scatter, float *packed, void *stream);
+
 extern "C" int ppo_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
                                  int64_t step, double lr, double beta1, double beta2, double eps, float max_grad_norm,
                                  float grad_div, void *workspace, float *grad_norm_out, void *stream)
+{
+    return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, max_grad_norm, grad_div, workspace,
+                     grad_norm_out, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int ppo_adam_step_scatter_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                         int64_t step, double lr, double beta1, double beta2, double eps,
+                                         float max_grad_norm, float grad_div, void *workspace, float *grad_norm_out,
+                                         const int32_t *scatter, int64_t n_scatter, float *packed, void *stream)
+{
+    if (n_scatter < 0 || n_scatter > n || (n_scatter > 0 && (!scatter || !packed)))
+        return ppo::fail(PPO_E_INVALID, "ppo_adam_step_scatter_f32: bad scatter table");
+    return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, max_grad_norm, grad_div, workspace,
+                     grad_norm_out, scatter, n_scatter, packed, stream);
+}
+
+static int adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, double lr,
+                     double beta1, double beta2, double eps, float max_grad_norm, float grad_div, void *workspace,
+                     float *grad_norm_out, const int32_t *scatter, int64_t n_scatter, float *packed, void *stream)
 {
     using namespace ppo;
     if (n < 0 || step < 1) return fail(PPO_E_INVALID, "ppo_adam_step_f32: n < 0 or step < 1");
@@ -141,6 +185,6 @@ extern "C" int ppo_adam_step_f32(float *params, const float *grads, float *exp_a
     grid = grid > 1024 ? 1024 : grid;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, partials, np,
                        (float)lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)bc1,
-                       (float)sqrt(bc2), max_grad_norm, grad_div, grad_norm_out);
+                       (float)sqrt(bc2), max_grad_norm, grad_div, grad_norm_out, scatter, n_scatter, packed);
     return check_launch("adam_kernel");
 }

@@ -44,6 +44,10 @@ WGRAD_POOLED_DY = int(os.environ.get("PPO_AMD_WGRAD_POOLED_DY", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
+# the optimiser step writes the updated convolution weights into their packed layouts too (no re-pack launch per step).
+# Measured and NOT kept (0): 1.118 ms per training step against 1.094 with the separate 5 us pack launch - 2 x 98 k
+# scattered 4-byte writes from the first hundred workgroups of the Adam launch cost more than the coalesced re-pack
+ADAM_SCATTER = int(os.environ.get("PPO_AMD_ADAM_SCATTER", "0"))
 # The two residual blocks of a stack as one launch with the image resident in LDS (csrc/stack_fused.hip), where the
 # geometry has a kernel (32 channels at 11x11) and the packed weights exist; 0 = four convolution launches.
 FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
@@ -386,7 +390,7 @@ class DualHeadNet:
     def _build_packed_weights(self):
         """One buffer with, per convolution, the forward kernels' A operand and the backward-data kernels' (flipped,
         transposed) one in per-lane order, plus the job table of the launch that refreshes all of them."""
-        self._pk, self._pack_table, self._packed_dirty = {}, None, False
+        self._pk, self._pack_table, self._packed_dirty, self._scatter = {}, None, False, None
         if not PACKED_WEIGHTS or self.encoder_kind != "impala":
             return
         jobs, total = [], 0
@@ -408,6 +412,33 @@ class DualHeadNet:
             table[k] = _lib.PackJob(_p(self.params[wname + ".weight"]), _p(view), cin, cout, transposed)
         self._pack_table = table
         self._packed_dirty = True
+
+    def _scatter_table(self):
+        """[n_conv, 2] int32 (device): for every element of the flat buffer's convolution head the one or two slots of
+        the packed buffer that hold it (-1: none - biases, alignment padding), so that the optimiser step can refresh
+        the packed operands itself (ppo_adam_step_scatter_f32).  Found by packing a buffer of element numbers once."""
+        if self._scatter is None and self._pack_table is not None:
+            n_conv = int(self.early_grad_offset)
+            keep = self.flat[:n_conv].clone()
+            self.flat[:n_conv] = torch.arange(1, n_conv + 1, dtype=torch.float32, device=self.device)  # exact below 2^24
+            self._packed_dirty = True
+            self._refresh_packed()
+            slots = self._packed.cpu().numpy().astype(np.int64)
+            self.flat[:n_conv] = keep
+            self._packed_dirty = True
+            self._refresh_packed()
+            pos = np.flatnonzero(slots > 0)
+            src = slots[pos] - 1
+            order = np.argsort(src, kind="stable")
+            src, pos = src[order], pos[order]
+            first = np.r_[True, src[1:] != src[:-1]]
+            second = ~first
+            assert not (second[1:] & second[:-1]).any(), "a weight sits in more than two packed slots"
+            table = np.full((n_conv, 2), -1, np.int32)
+            table[src[first], 0] = pos[first]
+            table[src[second], 1] = pos[second]
+            self._scatter = (torch.from_numpy(table).to(self.device), n_conv)
+        return self._scatter
 
     def mark_weights_changed(self):
         """Call after writing convolution weights other than through adam_step / load_state_dict."""
@@ -1083,7 +1114,11 @@ class DualHeadNet:
         `state`: a separate set of Adam moments over the same parameters (the reference's distil optimiser,
         rl/rollout.py:136-141); default is the net's own."""
         ws = self._ws("adam_ws", self.lib.ppo_adam_workspace_bytes())
-        self.mark_weights_changed()
+        scatter = self._scatter_table() if ADAM_SCATTER else None
+        if scatter is None:
+            self.mark_weights_changed()
+        elif self._packed_dirty:
+            self._refresh_packed()  # weights written by hand since the last step: start from a consistent packed copy
         if state is not None:
             state.ensure(self.flat)
             state.step += 1
@@ -1094,6 +1129,12 @@ class DualHeadNet:
                 self.exp_avg_sq = torch.zeros_like(self.flat)
             self._adam_step += 1
             m, v, step = self.exp_avg, self.exp_avg_sq, self._adam_step
+        if scatter is not None:
+            # the step also refreshes the convolution kernels' packed operands: no re-pack launch before the next forward
+            self._call("ppo_adam_step_scatter_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step,
+                       float(lr), float(beta1), float(beta2), float(eps), float(max_grad_norm), float(grad_div), _p(ws),
+                       _p(grad_norm_out), _p(scatter[0]), scatter[1], _p(self._packed))
+            return
         self._call("ppo_adam_step_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step, float(lr),
                    float(beta1), float(beta2), float(eps), float(max_grad_norm), float(grad_div), _p(ws),
                    _p(grad_norm_out))

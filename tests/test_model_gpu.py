@@ -393,3 +393,32 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
         torch.cuda.synchronize()
         assert torch.equal(a.grad, again), "the batched weight-gradient launch is not deterministic"
         assert {("bwd", 0), ("bwd", 1), ("full_bwd", 2)} <= set(a._tail_ptrs), "the fused backward did not engage"
+
+
+def test_optimiser_step_keeps_the_packed_convolution_weights_fresh(gold, monkeypatch):
+    """ppo_adam_step_scatter_f32 writes every updated convolution weight into the kernels' pre-packed MFMA operand
+    layouts as well (forward, and flipped / transposed for backward-data), so no re-pack launch runs per step: after a
+    few steps the packed buffer must be, bit for bit, what ppo_conv3x3_pack_weights_f32 makes of the parameters."""
+    g, meta = gold
+    monkeypatch.setattr(models, "ADAM_SCATTER", 1)  # opt-in path (default off: measured slower than the re-pack launch)
+    net = make_net(meta)
+    assert net._scatter_table() is not None
+    table, n_conv = net._scatter_table()
+    t = table.cpu().numpy()
+    n_weights = sum(int(np.prod(v["shape"])) for k, v in meta["params"].items() if k.startswith("encoder.stacks") and k.endswith("weight"))
+    assert int((t[:, 0] >= 0).sum()) == n_weights and int((t[:, 1] >= 0).sum()) == n_weights - 16 * 4 * 9  # no transposed first conv
+    x = torch.from_numpy(g["mb0_prev_state"]).cuda()
+    B = x.shape[0]
+    for _ in range(3):
+        out = net.forward(x)
+        net.ppo_minibatch(x, torch.zeros(B, dtype=torch.int32, device="cuda"), out["log_policy"][:, 0].contiguous(),
+                          out["log_policy"].clone(), torch.ones(B, device="cuda"), torch.zeros(B, 1, device="cuda"))
+        net.adam_step()
+    torch.cuda.synchronize()
+    assert not net._packed_dirty
+    kept = net._packed.clone()
+    net._packed.zero_()
+    net.mark_weights_changed()
+    net._refresh_packed()
+    torch.cuda.synchronize()
+    assert torch.equal(kept, net._packed)
