@@ -495,6 +495,13 @@ void ppo_synth_env_destroy(void *env);
 int ppo_synth_env_reset(void *env, uint8_t *obs_out);
 int ppo_synth_env_step(void *env, const int32_t *actions, uint8_t *obs_out, float *reward_out, uint8_t *done_out,
                        int32_t *time_out, float *ep_score_out, int32_t *ep_len_out);
+/* ppo_synth_env_step + the upload of the new observations: the host-to-device copy of each 1 / n_chunks of the envs is
+ * queued on `stream` as soon as it has been generated, while the worker threads generate the rest (north_star: "pinned
+ * async obs copies into a GPU-resident rollout buffer").  obs_out: pinned host memory; obs_dev: device address of env 0's
+ * observation ([n_envs, obs_bytes], e.g. a row slice of Runner.all_obs, rl/rollout.py:189-250). */
+int ppo_synth_env_step_upload(void *env, const int32_t *actions, uint8_t *obs_out, float *reward_out, uint8_t *done_out,
+                              int32_t *time_out, float *ep_score_out, int32_t *ep_len_out, void *obs_dev, int n_chunks,
+                              void *stream);
 /* Checkpointing, the counterpart of the worker envs' save_state / restore_state (rl/hybridVecEnv.py:84-105,
  * rl/utils.py:977-1038): per-env generator step count [n] i64, steps since reset [n] i32, running episode score
  * [n] f32.  set_state also rewrites obs_out [n_envs, obs_bytes] with the observation those counters imply. */

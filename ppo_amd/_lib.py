@@ -58,6 +58,7 @@ SIGNATURES = {
     "ppo_synth_env_destroy": (None, [_vp]),
     "ppo_synth_env_reset": (_i, [_vp, _vp]),
     "ppo_synth_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ppo_synth_env_step_upload": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ppo_synth_env_get_state": (_i, [_vp, _vp, _vp, _vp]),
     "ppo_synth_env_set_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "ppo_ppo_loss_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),

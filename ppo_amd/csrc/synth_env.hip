@@ -50,6 +50,12 @@ struct SynthEnv {
     float *ep_score_out = nullptr;
     int32_t *ep_len_out = nullptr;
     bool is_reset = false;
+    // chunked step (ppo_synth_env_step_upload): envs are handed out in index order in blocks of `block`, and
+    // chunk_left[c] counts the blocks of chunk c still running, so the caller can upload chunk c while later ones
+    // are still being generated
+    int block = 0, n_chunks = 0, blocks_per_chunk = 0;
+    std::atomic<int> next_block{0};
+    std::atomic<int> chunk_left[16];
 
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -127,10 +133,22 @@ struct SynthEnv {
                 if (stop) return;
                 seen = generation;
             }
-            const int per = (n_envs + n_workers - 1) / n_workers;
-            const int lo = idx * per;
-            const int hi = lo + per < n_envs ? lo + per : n_envs;
-            if (lo < hi) run_range(lo, hi);
+            if (block > 0) {
+                // dynamic, in-order hand-out: the first chunk's envs are all done before most of the last chunk's start
+                const int n_blocks = (n_envs + block - 1) / block;
+                for (;;) {
+                    const int b = next_block.fetch_add(1, std::memory_order_relaxed);
+                    if (b >= n_blocks) break;
+                    const int lo = b * block, hi = lo + block < n_envs ? lo + block : n_envs;
+                    run_range(lo, hi);
+                    chunk_left[b / blocks_per_chunk].fetch_sub(1, std::memory_order_release);
+                }
+            } else {
+                const int per = (n_envs + n_workers - 1) / n_workers;
+                const int lo = idx * per;
+                const int hi = lo + per < n_envs ? lo + per : n_envs;
+                if (lo < hi) run_range(lo, hi);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (--pending == 0) cv_done.notify_all();
@@ -148,6 +166,20 @@ struct SynthEnv {
         pending = (int)workers.size();
         ++generation;
         cv_start.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+
+    void start()  // dispatch without waiting
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        pending = (int)workers.size();
+        ++generation;
+        cv_start.notify_all();
+    }
+
+    void join()
+    {
+        std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
@@ -213,6 +245,63 @@ extern "C" int ppo_synth_env_step(void *h, const int32_t *actions, uint8_t *obs_
     e->ep_len_out = ep_len_out;
     e->dispatch();
     return PPO_OK;
+}
+
+// Step all envs and upload their observations: the host-to-device copy of chunk c (1 / n_chunks of the envs, in index
+// order) is queued on `stream` as soon as that chunk's observations exist, while the worker threads are still generating
+// the later chunks - "pinned async obs copies into a GPU-resident rollout buffer" with the copy under the stepping
+// instead of after it.  obs_out must be pinned host memory, obs_dev the device destination of env 0.
+extern "C" int ppo_synth_env_step_upload(void *h, const int32_t *actions, uint8_t *obs_out, float *reward_out,
+                                         uint8_t *done_out, int32_t *time_out, float *ep_score_out, int32_t *ep_len_out,
+                                         void *obs_dev, int n_chunks, void *stream)
+{
+    auto *e = static_cast<SynthEnv *>(h);
+    if (!e || !obs_out || !obs_dev) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_step_upload: null");
+    if (n_chunks < 1 || n_chunks > 16) return ppo::fail(PPO_E_INVALID, "ppo_synth_env_step_upload: 1..16 chunks");
+    e->actions = actions;
+    e->obs = obs_out;
+    e->reward = reward_out;
+    e->done = done_out;
+    e->time_out = time_out;
+    e->ep_score_out = ep_score_out;
+    e->ep_len_out = ep_len_out;
+    hipStream_t st = ppo::as_stream(stream);
+    if (e->workers.empty()) {
+        e->run_range(0, e->n_envs);
+        hipError_t err = hipMemcpyAsync(obs_dev, obs_out, (size_t)e->n_envs * e->obs_bytes, hipMemcpyHostToDevice, st);
+        return err == hipSuccess ? PPO_OK : ppo::fail(PPO_E_HIP, "ppo_synth_env_step_upload: %s", hipGetErrorString(err));
+    }
+    // blocks of 2 envs; a chunk is a whole number of blocks
+    const int block = 2;
+    const int n_blocks = (e->n_envs + block - 1) / block;
+    const int bpc = (n_blocks + n_chunks - 1) / n_chunks;
+    const int chunks = (n_blocks + bpc - 1) / bpc;
+    e->block = block;
+    e->blocks_per_chunk = bpc;
+    e->n_chunks = chunks;
+    e->next_block.store(0);
+    for (int c = 0; c < chunks; ++c) {
+        const int first = c * bpc, last = (c + 1) * bpc < n_blocks ? (c + 1) * bpc : n_blocks;
+        e->chunk_left[c].store(last - first);
+    }
+    e->start();
+    int rc = PPO_OK;
+    for (int c = 0; c < chunks; ++c) {
+        while (e->chunk_left[c].load(std::memory_order_acquire) > 0) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        const int64_t lo = (int64_t)c * bpc * block;
+        int64_t hi = (int64_t)(c + 1) * bpc * block;
+        hi = hi < e->n_envs ? hi : e->n_envs;
+        hipError_t err = hipMemcpyAsync(static_cast<uint8_t *>(obs_dev) + lo * e->obs_bytes, obs_out + lo * e->obs_bytes,
+                                        (size_t)(hi - lo) * e->obs_bytes, hipMemcpyHostToDevice, st);
+        if (err != hipSuccess && rc == PPO_OK) rc = ppo::fail(PPO_E_HIP, "ppo_synth_env_step_upload: %s", hipGetErrorString(err));
+    }
+    e->join();
+    e->block = 0;
+    return rc;
 }
 
 // Checkpointing (rl/hybridVecEnv.py:84-105 save_state / restore_state of the worker envs): the generator state of an
