@@ -51,8 +51,14 @@ constexpr int pad_mod32(int v, int target) { return v + ((target - v % 32) + 32)
 #ifndef PPO_TUNE_WGRAD_PERCU
 #define PPO_TUNE_WGRAD_PERCU 2
 #endif
+#ifndef PPO_TUNE_WGRAD_NBUF_ONEBAND
+#define PPO_TUNE_WGRAD_NBUF_ONEBAND 1
+#endif
 template <int IN_MODE, int NBANDS>
-constexpr int wgrad_nbuf() { return (IN_MODE == IN_U8 || NBANDS == 1) ? 1 : PPO_TUNE_WGRAD_NBUF; }
+constexpr int wgrad_nbuf()
+{
+    return IN_MODE == IN_U8 ? 1 : (NBANDS == 1 ? PPO_TUNE_WGRAD_NBUF_ONEBAND : PPO_TUNE_WGRAD_NBUF);
+}
 // contiguous-run band layout (16-byte LDS-DMA) wherever both bands arrive by DMA
 template <int IN_MODE, bool DY_POOLED>
 constexpr bool wgrad_run() { return true; }  // (the halo-column layout remains for reference behind RUN = false)
