@@ -52,7 +52,15 @@ def test_rollout_fills_buffers_consistently(runner):
     assert len(torch.unique(act)) == r.n_actions
 
 
-def test_returns_match_oracle_bitwise(runner):
+def _ulps(x, ref):
+    """Distance in float32 units in the last place (monotone integer view of the bit patterns)."""
+    def key(a):
+        i = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+        return np.where(i < 0, np.int64(-2**31) - i, i)
+    return np.abs(key(x) - key(ref))
+
+
+def test_returns_match_oracle_within_2_ulp(runner):
     r = runner
     r.calculate_returns()
     torch.cuda.synchronize()
@@ -62,7 +70,13 @@ def test_returns_match_oracle_bitwise(runner):
                                 args.gamma, args.lambda_policy, args.lambda_value)
     a = r.advantage.cpu().numpy()
     b = r.returns.view(N, A).cpu().numpy()
-    # A=16 takes the tiles regime: float64 composition, within 2 ulp / 1e-5 of the reference order
+    # A = 16 takes the tiles regime (per-segment affine maps composed in float64, rounded once): not the reference's
+    # operation order, so not bit-exact like the columns regime (tests/test_gae_gpu.py), but within 2 ulp of it for
+    # bool terminals - and far inside the reference's own 1e-5 criterion
+    assert int(_ulps(a, oa).max()) <= 2, int(_ulps(a, oa).max())
+    # returns = advantage + value: 2 units in the last place of the larger operand (the sum itself may cancel)
+    unit = np.spacing(np.maximum(np.abs(oa), np.abs(v[:N])).astype(np.float32))
+    assert (np.abs(b.astype(np.float64) - orr) <= 2.0 * unit).all()
     assert np.abs(a - oa).max() <= 1e-5 * np.abs(oa).max() and np.abs(b - orr).max() <= 1e-5 * np.abs(orr).max()
 
 
