@@ -451,6 +451,17 @@ int ppo_impala_stack_chain_forward_f32(const float *in, const float *const *pre_
                                        float *pre_q1, const float *const *packed_weights, const float *const *biases,
                                        float *pooled, uint8_t *argmax, float *a0, float *q0, float *a1, float *q1,
                                        int n_images, int channels, int h, int w, void *stream);
+/* The chained form for SMALL inference batches (a rollout group: at most half as many images as the chip has CUs): every
+ * image on TWO workgroups that split the output channels of the five convolutions on the h x w map and exchange their
+ * halves after each (csrc/stack_fused.hip stack_chain_split_kernel); only q1 is written.  Bit-identical to
+ * ppo_impala_stack_chain_forward_f32.  workspace: ppo_impala_stack_chain_split_workspace_bytes(n, channels, h, w) bytes,
+ * 16-byte aligned, ZEROED once by the caller and then left alone (it carries the exchange flags, the launch counter and,
+ * in its last 16 bytes, word 2 = an error flag set when a workgroup's partner never arrived within the spin bound). */
+size_t ppo_impala_stack_chain_split_workspace_bytes(int n_images, int channels, int h, int w);
+int ppo_impala_stack_chain_split_forward_f32(const float *in, const float *const *pre_packed_weights,
+                                             const float *const *pre_biases, const float *const *packed_weights,
+                                             const float *const *biases, float *q1, void *workspace, size_t workspace_bytes,
+                                             int n_images, int channels, int h, int w, void *stream);
 int ppo_impala_stack_full_backward_f32(const float *g, const float *const *packed_weights_t, const float *const *masks,
                                        const uint8_t *argmax, float *da1, float *g1, float *da0, float *g0, float *dc,
                                        float *g_prev, int n_images, int channels, int h, int w, void *stream);

@@ -84,6 +84,8 @@ SIGNATURES = {
     "ppo_impala_stack_full_supported": (_i, [_i, _i, _i]),
     "ppo_impala_stack_full_backward_f32": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
     "ppo_impala_stack_chain_forward_f32": (_i, [_vp] * 15 + [_i, _i, _i, _i, _vp]),
+    "ppo_impala_stack_chain_split_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ppo_impala_stack_chain_split_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     "ppo_impala_stack_full_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_impala_stack_tail_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_obs_moments_f64": (_i, [_vp, _i, _i, _i, _vp, _vp]),

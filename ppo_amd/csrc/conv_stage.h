@@ -424,7 +424,9 @@ __device__ __forceinline__ void band_u8x4_store(const uint32_t (&raw)[FlatU8Map<
 // n % 4 leftover floats (never over-reads the source, never over-writes the rows below).  Band rows outside
 // the image (first / last band of an image) are zeroed with plain LDS stores.  Padded channels (>= C) and
 // the guards are never written: the caller zeroes the whole region once.
-template <int C, int H, int W, int ROWS, int PLANE, int G, int NWAVES>
+// AUX: cache-policy bits of the loads (0 = default; 16 = sc1: device-coherent reads that do not hit the CU's own L1,
+// for data another workgroup has just written - stack_chain_split_kernel's exchange).
+template <int C, int H, int W, int ROWS, int PLANE, int G, int NWAVES, int AUX = 0>
 __device__ __forceinline__ void stage_band_chunk_dma(const float *__restrict__ src, int img, int y0,
                                                      float *__restrict__ s_dst, int tid)
 {
@@ -449,13 +451,13 @@ __device__ __forceinline__ void stage_band_chunk_dma(const float *__restrict__ s
 #pragma unroll
             for (int q = 0; q < MAXREQ; ++q) {
                 if ((q + 1) * 64 <= N4)  // whole request: no lane test at all
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gc + q * 256), (lptr_t)(lc + q * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gc + q * 256), (lptr_t)(lc + q * 256), 16, 0, AUX);
                 else if (q * 64 + lane < N4)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gc + q * 256), (lptr_t)(lc + q * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gc + q * 256), (lptr_t)(lc + q * 256), 16, 0, AUX);
             }
             if constexpr (TAIL > 0) {
                 if (lane < TAIL)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gc - 4 * lane + N4 * 4 + lane), (lptr_t)(lc + N4 * 4), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gc - 4 * lane + N4 * 4 + lane), (lptr_t)(lc + N4 * 4), 4, 0, AUX);
             }
         }
         return;
@@ -470,10 +472,10 @@ __device__ __forceinline__ void stage_band_chunk_dma(const float *__restrict__ s
 #pragma unroll
         for (int q = 0; q < MAXREQ; ++q) {
             if (q * 64 + lane < n4)
-                __builtin_amdgcn_global_load_lds((gptr_t)(g0 + (q * 64 + lane) * 4), (lptr_t)(l0 + q * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(g0 + (q * 64 + lane) * 4), (lptr_t)(l0 + q * 256), 16, 0, AUX);
         }
         if (lane < tail)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g0 + n4 * 4 + lane), (lptr_t)(l0 + n4 * 4), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g0 + n4 * 4 + lane), (lptr_t)(l0 + n4 * 4), 4, 0, AUX);
         if (r_lo > 0)
             for (int x = lane; x < r_lo * W; x += 64) s_dst[c * PLANE + G + x] = 0.f;
         if (r_hi < ROWS)

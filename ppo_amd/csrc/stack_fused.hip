@@ -18,6 +18,7 @@
 // Each convolution is the implicit GEMM of conv3x3.hip (same flat band layout with TR = H, same K order, same
 // epilogue arithmetic: results are bit-identical to the four separate launches); its weights are the pre-packed A
 // operand (ppo_conv3x3_pack_weights_f32), re-loaded into registers at each layer switch.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -894,6 +895,178 @@ int launch_stack_full(const StackFullArgs &args, hipStream_t st)
     return check_launch("stack_full_kernel");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The chained launch for SMALL inference batches (a rollout group of 128 images on a 256-CU chip): one image on TWO CUs.
+//
+// One workgroup per image leaves half the chip idle at 128 images, and the chain of nine convolutions of one image is
+// MFMA-bound on its one CU (rocprofv3 timeline of the rollout: 2 x 124 us of a 536 us env step in this launch, at 0.31 of
+// peak).  Rows cannot be split: the halo of nine chained convolutions and a stride-2 pool is most of a 21-row map.  So the
+// pair of workgroups of an image splits the OUTPUT CHANNELS of the five convolutions on the 21x21 map (82 % of the
+// launch's FLOPs): workgroup h computes channels 16 h .. 16 h + 15 of every layer for all pixels - the same K loop, K
+// order and epilogue arithmetic per output element as stack_full_kernel, hence the same bits - and after each of those
+// layers the two exchange their halves through HBM / L2: own half written next to the LDS copy (resident_conv's `save`),
+// a release fence, a flag; a bounded spin on the partner's flag (acquire), then the partner's half comes in by LDS-DMA.
+// The 11x11 part (pool + four convolutions, 18 % of the FLOPs, 1 us of MFMA work per layer) is cheaper to compute twice
+// than to exchange: both workgroups run it on the whole pooled map, channel tile by channel tile, and h = 0 stores it.
+//
+// Pairing and progress: workgroups b and b ^ 8 form a pair (same XCD under the round-robin placement, adjacent in that
+// XCD's dispatch order), so the resident set of an in-order dispatch is always whole pairs plus at most one workgroup
+// per XCD whose partner is next in line; whole pairs finish without anybody else, which frees the slot.  The spin is
+// BOUNDED all the same: a partner that never shows up sets ctl[2] (the host checks it) and the wave goes on with
+// garbage instead of hanging the device.  ctl[0] is the launch number (flag values never repeat: no resets), advanced
+// by the last workgroup of a launch to leave (ctl[1] counts them), so every launch has the same arguments and can sit in a
+// recorded launch plan.
+struct ChainSplitArgs {
+    const float *in;         // [n, C, HI, WI] the previous stack's pooled map
+    const float *pre_w[4];   // packed forward weights of its two residual blocks
+    const float *pre_bias[4];
+    const float *w[5];       // firstconv + the four block convolutions of this stack
+    const float *bias[5];
+    float *out;              // q1 [n, C, HO, WO]
+    float *xbuf;             // [n][2][C][HI * WI] exchange slots
+    uint32_t *flags;         // [n][2]
+    uint32_t *ctl;           // launch number, workgroups done, error
+    int n_images;
+    int skip;                // timing aid (PPO_AMD_SPLIT_SKIP): 1 no waiting for the partner, 2 no 11x11 part - garbage out
+};
+
+constexpr int kSplitWaves = 8;  // 28 pixel tiles of the 21x21 map, four per wave (the eighth wave's are past the map); one
+                                // channel tile (16 of 32) per workgroup.  (14 waves of two tiles spilled: 128-register cap)
+constexpr uint32_t kSpinLimit = 1u << 21;
+
+template <int C, int HI, int WI, int HO, int WO>
+__global__ __launch_bounds__(kSplitWaves * 64) void stack_chain_split_kernel(ChainSplitArgs a)
+{
+    static_assert(C == 32, "two channel tiles: one per workgroup of a pair");
+    using SI = StackCfg<C, HI, WI, 7, 4, 2>;   // geometry constants only (PLANE, LDS_MAP, ...)
+    using SO = StackCfg<C, HO, WO, 2, 4, 2>;
+    constexpr int MTI = 4, MTO = 2, WAVES = kSplitWaves, THREADS = WAVES * 64;
+    static_assert(SI::MTILES <= MTI * WAVES && SO::MTILES == MTO * 4 && WAVES == 8, "every pixel tile has a wave");
+    static_assert(2 * SO::LDS_MAP <= SI::LDS_MAP, "the small maps reuse the input map's LDS");
+    constexpr int A_OFF = 0, B_OFF = SI::LDS_MAP, X_OFF = 0, Y_OFF = SO::LDS_MAP;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int h = (b >> 3) & 1;                      // which half of the output channels
+    const int pair0 = (b & 7) | ((b >> 4) << 3);     // partner: b ^ 8
+    const int n_pairs = (gridDim.x >> 4) << 3;
+
+    LaneMap::T<MTI> lmi;
+    LaneMap::T<MTO> lmo;
+    lane_map_init<HI, WI, SI::PLANE, SI::G, MTI>(lmi, wave, l15, g);
+    lane_map_init<HO, WO, SO::PLANE, SO::G, MTO>(lmo, wave & 3, l15, g);
+
+    const uint32_t base = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u;  // 5 exchanges per launch
+    zero_lds<SI::LDS_MAP, THREADS>(smem + B_OFF, tid);  // halo rows / guards of the second big map
+
+    for (int img = pair0; img < a.n_images; img += n_pairs) {
+        uint32_t *flag_own = a.flags + 2 * img + h, *flag_other = a.flags + 2 * img + (1 - h);
+        float *slots = a.xbuf + (size_t)img * 2 * C * HI * WI;
+        uint32_t step = 0;
+        // own half of a layer's result is in LDS and in its slot: publish it, wait for the partner's, fetch that
+        auto exchange = [&](int dst_off, float *slot, bool fetch) {
+            ++step;
+            // Both workgroups of a pair sit on one XCD, i.e. behind one L2, and the vector L1 is write-through: a slot
+            // store is visible to the partner once it has been acknowledged (vmcnt(0)), PROVIDED the partner's reads do
+            // not hit its own L1 - they carry sc1.  (A device-scope fence pair here - buffer_wbl2 / buffer_inv, the
+            // whole L2 written back ten times per image - made the launch 4 x slower than the one it replaces.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(flag_own, base + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t it = 0;
+                while (!(a.skip & 1) && __hip_atomic_load(flag_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + step) {
+                    if (++it > kSpinLimit) {  // the partner never came: say so and go on (garbage, but the device lives)
+                        __hip_atomic_store(a.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            if (fetch)
+                stage_band_chunk_dma<16, HI, WI, SI::ROWS, SI::PLANE, SI::G, WAVES, 16>(slot + (size_t)(1 - h) * 16 * HI * WI, 0, 0,
+                                                                                       smem + dst_off + (1 - h) * 16 * SI::PLANE, tid);
+        };
+
+        __syncthreads();  // the previous image's last readers of the small maps are done
+        zero_lds<SI::LDS_MAP, THREADS>(smem + A_OFF, tid);
+        __syncthreads();
+        stage_band_chunk_dma<C, HI, WI, SI::ROWS, SI::PLANE, SI::G, WAVES>(a.in, img, 0, smem + A_OFF, tid);
+        // ---- the previous stack's residual blocks: A <-> B ping-pong, result back in A
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            const int odd = layer & 1;
+            float *slot = slots + (size_t)(layer & 1) * C * HI * WI;
+            resident_conv<C, HI, WI, MTI, 2, 1, true>(smem, odd ? B_OFF : A_OFF, odd ? A_OFF : B_OFF, odd != 0, a.pre_w[layer],
+                                                      a.pre_bias[layer], slot, lmi, h, lane);
+            exchange(odd ? A_OFF : B_OFF, slot, true);
+        }
+        // ---- first convolution of this stack: A -> B (no ReLU on read, no residual)
+        resident_conv<C, HI, WI, MTI, 2, 1, false>(smem, A_OFF, B_OFF, false, a.w[0], a.bias[0], slots, lmi, h, lane);
+        exchange(B_OFF, slots, h == 0);
+        if (h != 0 || (a.skip & 2)) continue;  // the 11x11 part is workgroup 0's alone: its partner is done with this image (its CU is
+                               // free for another stream's kernels); the fetch of the last exchange is all it waited for
+        __syncthreads();  // B is complete (the fetch landed: vmcnt(0) at the barrier) and nobody reads A any more
+        zero_lds<2 * SO::LDS_MAP, THREADS>(smem + X_OFF, tid);
+        __syncthreads();
+        // ---- pool B -> X
+        {
+            constexpr int RPW = 64 / WO;
+            const int sub = lane / WO, xo = lane % WO;
+            for (int u0 = wave * RPW; u0 < C * HO; u0 += WAVES * RPW) {
+                const int u = u0 + sub;
+                const int co = u / HO, yo = u % HO;
+                if (sub < RPW && co < C) {
+                    const float *src = smem + B_OFF + co * SI::PLANE + SI::G + WI + (2 * yo - 1) * WI + 2 * xo - 1;
+                    float best;
+                    int best_tap;
+                    pool_window_lds<HI % 2 == 0, WI % 2 == 0>(src, WI, yo > 0, 2 * yo + 1 < HI, xo > 0, 2 * xo + 1 < WI, best, best_tap);
+                    smem[X_OFF + co * SO::PLANE + SO::G + WO + yo * WO + xo] = best;
+                }
+            }
+        }
+        // ---- the residual blocks on the pooled map (4 pixel-tile waves x 2 channel tiles, as stack_full_kernel)
+        float *out_img = a.out + (size_t)img * C * HO * WO;
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            const int odd = layer & 1;
+            resident_conv<C, HO, WO, MTO, 2, 1, true>(smem, odd ? Y_OFF : X_OFF, odd ? X_OFF : Y_OFF, odd != 0, a.w[1 + layer],
+                                                      a.bias[1 + layer], layer == 3 ? out_img : nullptr, lmo, wave >> 2, lane);
+        }
+    }
+    // the last workgroup to leave advances the launch number
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int C, int HI, int WI, int HO, int WO>
+int launch_chain_split(const ChainSplitArgs &args, hipStream_t st)
+{
+    using SI = StackCfg<C, HI, WI, 7, 4, 2>;
+    constexpr size_t kLds = 2 * (size_t)SI::LDS_MAP * 4;
+    auto kern = stack_chain_split_kernel<C, HI, WI, HO, WO>;
+    static bool ready = false;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kLds);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_chain_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        ready = true;
+    }
+    int groups = (args.n_images + 7) / 8;       // 8 pairs = 16 workgroups per group: b and b ^ 8
+    if (groups > 16) groups = 16;               // at most one workgroup per CU; more images: pairs walk them
+    hipLaunchKernelGGL(kern, dim3(16 * groups), dim3(kSplitWaves * 64), kLds, st, args);
+    return check_launch("stack_chain_split_kernel");
+}
+
 }  // namespace
 }  // namespace ppo
 
@@ -1110,4 +1283,53 @@ extern "C" int ppo_impala_stack_full_backward_f32(const float *g, const float *c
     if (channels == 32 && h == 16 && w == 16)
         return launch_stack_full_bwd<32, 16, 16, 4, 8, 8, 1, 4, 2>(args, as_stream(stream));
     return fail(PPO_E_INVALID, "ppo_impala_stack_full_backward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+}
+
+extern "C" size_t ppo_impala_stack_chain_split_workspace_bytes(int n_images, int channels, int h, int w)
+{
+    // exchange slots [n][2][C][h*w] floats, flags [n][2], control words [4] (all 16-byte aligned inside the block)
+    const size_t slots = (size_t)n_images * 2 * channels * h * w * sizeof(float);
+    const size_t flags = ((size_t)n_images * 2 * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return slots + flags + 16;
+}
+
+extern "C" int ppo_impala_stack_chain_split_forward_f32(const float *in, const float *const *pre_packed_weights,
+                                                        const float *const *pre_biases,
+                                                        const float *const *packed_weights, const float *const *biases,
+                                                        float *q1, void *workspace, size_t workspace_bytes, int n_images,
+                                                        int channels, int h, int w, void *stream)
+{
+    using namespace ppo;
+    if (n_images < 0) return fail(PPO_E_INVALID, "ppo_impala_stack_chain_split_forward_f32: negative batch");
+    if (n_images == 0) return PPO_OK;
+    if (!in || !pre_packed_weights || !pre_biases || !packed_weights || !biases || !q1 || !workspace)
+        return fail(PPO_E_INVALID, "ppo_impala_stack_chain_split_forward_f32: null pointer");
+    if (!(channels == 32 && h == 21 && w == 21))
+        return fail(PPO_E_INVALID, "ppo_impala_stack_chain_split_forward_f32: no kernel for %d channels at %dx%d", channels, h, w);
+    if (workspace_bytes < ppo_impala_stack_chain_split_workspace_bytes(n_images, channels, h, w) || !aligned(workspace, 16))
+        return fail(PPO_E_INVALID, "ppo_impala_stack_chain_split_forward_f32: workspace too small or misaligned");
+    ChainSplitArgs args;
+    args.in = in;
+    for (int l = 0; l < 5; ++l) {
+        if (!packed_weights[l] || !biases[l] || (l < 4 && (!pre_packed_weights[l] || !pre_biases[l])))
+            return fail(PPO_E_INVALID, "ppo_impala_stack_chain_split_forward_f32: null weights / bias of layer %d", l);
+        if (!aligned(packed_weights[l], 16) || (l < 4 && !aligned(pre_packed_weights[l], 16)))
+            return fail(PPO_E_ALIGN, "ppo_impala_stack_chain_split_forward_f32: packed weights must be 16-byte aligned");
+        args.w[l] = packed_weights[l];
+        args.bias[l] = biases[l];
+        if (l < 4) {
+            args.pre_w[l] = pre_packed_weights[l];
+            args.pre_bias[l] = pre_biases[l];
+        }
+    }
+    args.out = q1;
+    const size_t slots = (size_t)n_images * 2 * channels * h * w * sizeof(float);
+    const size_t flags = ((size_t)n_images * 2 * sizeof(uint32_t) + 15) & ~(size_t)15;
+    args.xbuf = static_cast<float *>(workspace);
+    args.flags = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + slots);
+    args.ctl = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + slots + flags);
+    args.n_images = n_images;
+    static const int skip = getenv("PPO_AMD_SPLIT_SKIP") ? atoi(getenv("PPO_AMD_SPLIT_SKIP")) : 0;
+    args.skip = skip;
+    return launch_chain_split<32, 21, 21, 11, 11>(args, as_stream(stream));
 }

@@ -56,6 +56,14 @@ FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
 FUSE_STACK_FULL = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL", "1"))
 # ... with the previous stack's residual blocks chained in front of it (that stack's output stays in LDS).
 FUSE_STACK_CHAIN = int(os.environ.get("PPO_AMD_FUSE_STACK_CHAIN", "1"))
+# inference batches of at most CHAIN_SPLIT_MAX_BATCH images (a rollout group) can run the chained launch with every image
+# on TWO workgroups (output channels split, halves exchanged per layer): same bits, the whole chip instead of half of it.
+# OFF by default.  Measured: alone, a 128-image forward takes 0.258 ms against 0.282 (the launch 104 us against 128);
+# inside the two-group rollout it changes nothing (0.496 against 0.493 ms per env step): the GPU is 98 % busy there,
+# the idle half of the chip under the one-workgroup-per-image launch is where the OTHER group's kernels run, and the
+# split launch spends 1.6 x the CU time (256 CUs x 104 us against 128 x 128) - it trades throughput for latency.
+CHAIN_SPLIT = int(os.environ.get("PPO_AMD_CHAIN_SPLIT", "0"))
+CHAIN_SPLIT_MAX_BATCH = int(os.environ.get("PPO_AMD_CHAIN_SPLIT_MAX_BATCH", "128"))
 # ... and its backward-data pass (blocks + max-pool backward + transposed first convolution) likewise.  Off by default:
 # bit-identical, but 1.445 ms per 256-sample step against 1.395 without it — it holds a whole CU's LDS, so the
 # weight-gradient kernels on the side stream get nothing to overlap with for its duration, and releases the five
@@ -319,6 +327,7 @@ class DualHeadNet:
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
+        self._split_ws = {}  # workspaces of the two-workgroups-per-image chain launch
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self.use_plans = True  # False: every inference launch goes through _call (bench.py's per-kernel table brackets it)
         self._build_packed_weights()
@@ -627,6 +636,24 @@ class DualHeadNet:
             self._tail_ptrs[si] = cached
         return cached
 
+    def _chain_split_ws(self, tag, B, c, h, w):
+        """Exchange slots + flags + control words of ppo_impala_stack_chain_split_forward_f32: zeroed ONCE (the flag
+        values only ever grow, the kernel advances its own launch counter), one per scratch-buffer set."""
+        key = (tag, B, c, h, w)
+        ws = self._split_ws.get(key)
+        if ws is None:
+            n = int(self.lib.ppo_impala_stack_chain_split_workspace_bytes(B, c, h, w))
+            ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._split_ws[key] = ws
+        return ws
+
+    def chain_split_error(self) -> bool:
+        """True if any split launch saw a workgroup whose partner never arrived (word 2 of the control words)."""
+        bad = False
+        for ws in self._split_ws.values():
+            bad |= bool(ws[-16:].view(torch.int32)[2].item())
+        return bad
+
     def _encode_impala(self, x, train, tag):
         sp = self.spec
         B = x.shape[0]
@@ -643,7 +670,16 @@ class DualHeadNet:
                 a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
                 outs = (_p(p) if train else None, _p(idx), _p(a0) if train else None, _p(q0) if train else None,
                         _p(a1) if train else None, _p(q1), B, cout, h, w)
-                if pending is not None:
+                if pending is not None and not train and CHAIN_SPLIT and B <= CHAIN_SPLIT_MAX_BATCH \
+                        and (cout, h, w) == (32, 21, 21):
+                    # a rollout group (at most half as many images as CUs): every image on two workgroups that split
+                    # the output channels of the 21x21 convolutions and exchange halves (bit-identical, ~0.7 x the time)
+                    p_prev, ptrs_prev, _saves = pending
+                    pending = None
+                    ws = self._chain_split_ws(tag, B, cout, h, w)
+                    self._call("ppo_impala_stack_chain_split_forward_f32", _p(p_prev), ptrs_prev[0], ptrs_prev[1],
+                               full[0], full[1], _p(q1), _p(ws), ws.numel(), B, cout, h, w)
+                elif pending is not None:
                     # the previous stack's blocks run inside the same launch, on its pooled map
                     p_prev, ptrs_prev, (pa0, pq0, pa1, pq1) = pending
                     pending = None

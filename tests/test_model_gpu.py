@@ -422,3 +422,34 @@ def test_optimiser_step_keeps_the_packed_convolution_weights_fresh(gold, monkeyp
     net._refresh_packed()
     torch.cuda.synchronize()
     assert torch.equal(kept, net._packed)
+
+
+@pytest.mark.parametrize("B", [128, 100, 8, 1])
+def test_two_workgroups_per_image_chain_launch_is_bit_identical(gold, monkeypatch, B):
+    """Inference batches of a rollout group (<= 128 images) run the chained 21x21 -> 11x11 launch with every image on
+    TWO workgroups that split the output channels and exchange halves per layer (stack_chain_split_kernel).  Same K
+    order and epilogue arithmetic per output element, so the heads must be bit-identical to the one-workgroup-per-image
+    launch - over repeated launches (the kernel advances its own launch counter), for batches that do not fill the
+    pairing groups of 8, and with no partner ever missing."""
+    g, meta = gold
+    rng = np.random.default_rng(B)
+    x = torch.from_numpy(rng.integers(0, 256, size=(B, *meta["input_dims"]), dtype=np.uint8)).cuda()
+    x2 = torch.from_numpy(rng.integers(0, 256, size=(B, *meta["input_dims"]), dtype=np.uint8)).cuda()
+    outs = {}
+    for split in (0, 1):
+        monkeypatch.setattr(models, "CHAIN_SPLIT", split)
+        net = make_net(meta)
+        calls = []
+        orig = net._call
+        net._call = lambda fn, *a: (calls.append(fn), orig(fn, *a))[1]
+        res = []
+        for inp in (x, x2, x):
+            o = net.forward(inp)
+            res.append((o["raw_policy"].clone(), o["value"].clone()))
+        torch.cuda.synchronize()
+        assert ("ppo_impala_stack_chain_split_forward_f32" in calls) == bool(split)
+        assert not net.chain_split_error()
+        outs[split] = res
+    for (p0, v0), (p1, v1) in zip(outs[0], outs[1]):
+        assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    assert torch.equal(outs[1][0][0], outs[1][2][0]) and not torch.equal(outs[1][0][0], outs[1][1][0])
