@@ -152,6 +152,17 @@ int ppo_conv3x3_pool_forward_packed_f32(const void *in, int in_mode, const float
                                         void *stream);
 
 /*
+ * One residual block, q' = q + conv1(relu(conv0(relu(q)))) (rl/impala.py:66-84), as ONE launch for inference on small
+ * batches (a rollout group): band by band, the intermediate map stays in LDS (csrc/conv3x3_block.hip).  packed0 / packed1:
+ * the two convolutions' pre-packed forward weights (ppo_conv3x3_pack_weights_f32), bias0 / bias1 their biases; in / out
+ * [n, channels, h, w].  Bit-identical to ppo_conv3x3_forward_packed_f32(in, RELU, conv0) followed by
+ * ppo_conv3x3_forward_packed_f32(., RELU, conv1, residual = in).
+ */
+int ppo_conv3x3_block_supported(int channels, int h, int w);
+int ppo_conv3x3_block_forward_packed_f32(const float *in, const float *packed0, const float *bias0, const float *packed1,
+                                         const float *bias1, float *out, int n, int channels, int h, int w, void *stream);
+
+/*
  * Weight and bias gradient of the same convolution (torch autograd of nn.Conv2d):
  *   dweight[o,i,ky,kx] (+)= sum_{n,y,x} dy[n,o,y,x] * f(in[n,i,y+ky-1,x+kx-1])    dbias[o] (+)= sum dy[n,o,y,x]
  * `in`/in_mode: the forward convolution's input and load transform.  workspace: scratch of at

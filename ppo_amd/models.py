@@ -80,6 +80,9 @@ FUSE_STACK_TAIL_BWD = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL_BWD", "7"))
 # FUSE_STACK16_MIN_BATCH keep the four launches.  Same bits either way.
 FUSE_STACK16 = int(os.environ.get("PPO_AMD_FUSE_STACK16", "1"))
 FUSE_STACK16_MIN_BATCH = int(os.environ.get("PPO_AMD_FUSE_STACK16_MIN_BATCH", "192"))
+# Below that batch an inference forward runs each 16-channel residual block as one launch (csrc/conv3x3_block.hip: band by
+# band, the intermediate map in LDS) instead of two convolution launches: a 128-image group is launch-cost-bound there.
+FUSE_BLOCK = int(os.environ.get("PPO_AMD_FUSE_BLOCK", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -727,6 +730,14 @@ class DualHeadNet:
                 a = self._buf(f"{tag}a{si}_{bi}", (B, cout, ho, wo))
                 qn = self._buf(f"{tag}q{si}_{bi}", (B, cout, ho, wo))
                 base = f"encoder.stacks.{si}.blocks.{bi}"
+                pk0, pk1 = self._pk.get((base + ".conv0", 0)), self._pk.get((base + ".conv1", 0))
+                if not train and FUSE_BLOCK and pk0 is not None and pk1 is not None \
+                        and self.lib.ppo_conv3x3_block_supported(cout, ho, wo):
+                    # inference below the whole-stack kernel's batch: both convolutions of the block in one launch
+                    self._call("ppo_conv3x3_block_forward_packed_f32", _p(q), _p(pk0), _p(self.params[base + ".conv0.bias"]),
+                               _p(pk1), _p(self.params[base + ".conv1.bias"]), _p(qn), B, cout, ho, wo)
+                    q = qn
+                    continue
                 self._conv(q, IN_RELU, base + ".conv0", a, None, B, cout, cout, ho, wo)
                 self._conv(a, IN_RELU, base + ".conv1", qn, q, B, cout, cout, ho, wo)
                 acts[f"q{si}_{bi}_in"], acts[f"a{si}_{bi}"] = q, a

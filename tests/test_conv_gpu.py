@@ -229,3 +229,39 @@ def test_uint8_scaling_is_the_exact_quotient_for_all_256_values(cin, hw):
     _lib.check(rc, "ppo_conv3x3_pool_forward_f32")
     want = F.max_pool2d(xb[:, :1].cpu().float() / 255.0, 3, 2, 1)
     assert torch.equal(pooled[:, :1].cpu(), want)
+
+
+@pytest.mark.parametrize("hw", [42, 32])
+@pytest.mark.parametrize("n", [1, 3, 37, 128, 300])  # up to 256 images: half-image items on 16 waves; above: bands on 8
+def test_residual_block_in_one_launch_is_the_two_convolutions_bitwise(hw, n):
+    """ppo_conv3x3_block_forward_packed_f32 (rl/impala.py:66-84, the inference form for small batches: band by band, the
+    intermediate map in LDS, halo rows of conv0 recomputed and rows outside the image zeroed as conv1's padding) against
+    conv0 then conv1 + skip through ppo_conv3x3_forward_packed_f32: identical bits, including the image's first and last
+    bands and a last band shorter than the others; and against torch within the fp32 conv tolerance."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    assert lib.ppo_conv3x3_block_supported(16, hw, hw) == 1 and lib.ppo_conv3x3_block_supported(32, 21, 21) == 0
+    g = torch.Generator(device=dev).manual_seed(hw * 7 + n)
+    c = 16
+    w0, w1 = (torch.randn(c, c, 3, 3, generator=g, device=dev) * 0.2 for _ in range(2))
+    b0, b1 = (torch.randn(c, generator=g, device=dev) for _ in range(2))
+    nf = lib.ppo_conv3x3_packed_floats(c, c, 0)
+    p0, p1 = torch.empty(nf, device=dev), torch.empty(nf, device=dev)
+    jobs = (_lib.PackJob * 2)(_lib.PackJob(_p(w0), _p(p0), c, c, 0), _lib.PackJob(_p(w1), _p(p1), c, c, 0))
+    _lib.check(lib.ppo_conv3x3_pack_weights_f32(ctypes.addressof(jobs), 2, _lib.current_stream()), "pack")
+    x = torch.randn(n, c, hw, hw, generator=g, device=dev)
+    a, want = torch.empty_like(x), torch.empty_like(x)
+    st = _lib.current_stream()
+    _lib.check(lib.ppo_conv3x3_forward_packed_f32(_p(x), 1, _p(p0), _p(b0), None, _p(a), n, c, c, hw, hw, st), "conv0")
+    _lib.check(lib.ppo_conv3x3_forward_packed_f32(_p(a), 1, _p(p1), _p(b1), _p(x), _p(want), n, c, c, hw, hw, st), "conv1")
+    got = torch.full_like(x, float("nan"))
+    _lib.check(lib.ppo_conv3x3_block_forward_packed_f32(_p(x), _p(p0), _p(b0), _p(p1), _p(b1), _p(got), n, c, hw, hw, st),
+               "block")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = x + F.conv2d(F.relu(F.conv2d(F.relu(x), w0, b0, padding=1)), w1, b1, padding=1)
+    assert _close(got, ref)
+    # no kernel for other shapes: an error, not a silent wrong answer
+    rc = lib.ppo_conv3x3_block_forward_packed_f32(_p(x), _p(p0), _p(b0), _p(p1), _p(b1), _p(got), n, c, hw, hw + 1, st)
+    assert rc != 0
