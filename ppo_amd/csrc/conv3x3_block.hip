@@ -70,7 +70,7 @@ __device__ __forceinline__ void band_k_loop(const float *__restrict__ src, const
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #if PPO_TUNE_BLOCK == 2  // timing aid: no LDS reads
-                    r[u][m] = hi_l[m] + (float)tap_off;
+                    r[u][m] = hi_l[m];
 #else
                     r[u][m] = src[base[m] + cs * 4 * PLANE + tap_off];
 #endif
@@ -89,11 +89,17 @@ __device__ __forceinline__ void band_k_loop(const float *__restrict__ src, const
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     float x = raw[j & 1][u][m];
+#if PPO_TUNE_BLOCK == 3  // timing aid: no ReLU / edge mask
+                    if (false) {
+#else
                     if (kx != 1) {
+#endif
                         const float hi = kx == 0 ? hi_l[m] : hi_r[m];
                         x = __builtin_amdgcn_fmed3f(x, 0.f, hi);
                     } else {
+#if PPO_TUNE_BLOCK != 3
                         x = relu1(x);
+#endif
                     }
                     bv[u][m] = x;
                 }
@@ -107,11 +113,7 @@ __device__ __forceinline__ void band_k_loop(const float *__restrict__ src, const
             if (s < KS) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-#if PPO_TUNE_BLOCK == 3  // timing aid: no MFMAs
-                    acc[m][0] = __builtin_fmaf(wa[s], bv[u][m], acc[m][0]);
-#else
                     acc[m] = mfma16(wa[s], bv[u][m], acc[m]);
-#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
