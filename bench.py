@@ -351,8 +351,10 @@ def _batch_of(fn, a):
         return a[15]
     if fn == "ppo_impala_stack16_forward_f32":
         return a[-4]
-    if fn == "ppo_dense_heads_forward_f32":
+    if fn in ("ppo_dense_heads_forward_f32", "ppo_dense_heads_act_forward_f32"):
         return a[9]
+    if fn == "ppo_conv3x3_block_forward_packed_f32":
+        return a[6]
     return None
 
 
@@ -407,6 +409,12 @@ def _describe_call(fn, a):
     if fn == "ppo_dense_heads_forward_f32":  # (x, relu_x, W, b, Wh, bh, relu_h, h, heads, M, K, H, NH, ws, ws_bytes)
         M, K, H, NH = a[9:13]
         return f"dense + heads fwd {M}x{K}x{H} (+{NH})", 2.0 * M * H * (K + NH), None
+    if fn == "ppo_dense_heads_act_forward_f32":  # the same + (n_actions, temperature, seed, offset, outputs...)
+        M, K, H, NH = a[9:13]
+        return f"dense + heads + action sampling fwd {M}x{K}x{H} (+{NH})", 2.0 * M * H * (K + NH), None
+    if fn == "ppo_conv3x3_block_forward_packed_f32":  # (in, pk0, b0, pk1, b1, out, n, c, h, w)
+        n, c, h, w = a[6:10]
+        return f"residual block fwd (2 conv) {c}ch {h}x{w}", 2 * _conv(n, c, c, h, w), None
     if fn == "ppo_gather_rows":
         return "gather observation rows", None, 2.0 * a[1] * a[4]
     if fn == "ppo_adam_step_f32":

@@ -245,6 +245,20 @@ int ppo_dense_heads_forward_f32(const float *x, int relu_x, const float *W, cons
                                 size_t workspace_bytes, void *stream);
 
 /*
+ * The same, and the rollout's action step on the finished head row in the same launch: what ppo_policy_act_f32 does
+ * with greedy = 0 and its own uniforms (log-softmax of the first n_actions head outputs, Gumbel-max sample keyed by
+ * (seed, offset + row * n_actions + a), raw logits, value heads; any output pointer may be NULL).  Bit-identical to
+ * ppo_dense_heads_forward_f32 followed by ppo_policy_act_f32 - and runs as exactly that when the product is not split
+ * or n_actions is not one of 4 / 6 / 15 / 18.  Replaces the tail of Runner.detached_batch_forward + sample_actions
+ * (rl/rollout.py:557-598, 636-650) for one env group.
+ */
+int ppo_dense_heads_act_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh,
+                                    const float *bh, int relu_h, float *h, float *heads, int M, int K, int H, int NH,
+                                    void *workspace, size_t workspace_bytes, int n_actions, float temperature,
+                                    uint64_t seed, uint64_t offset, float *log_policy, int32_t *actions, float *log_pac,
+                                    float *raw_policy, float *values, int n_value_heads, void *stream);
+
+/*
  * Backward of the fused heads in one launch: dh[B,H] = (dheads[B,NH] @ Wh[NH,H]) * [gate > 0] (gate [B,H] nullable: the
  * ReLU pre-activation), dWh[NH,H] = dheads^T @ f(hin) (f = ReLU when relu_in), dbh[NH] = column sums of dheads
  * (nullable), db_next[H] = column sums of dh (nullable: the bias gradient of the layer below when dh is final).

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "policy_act.h"
 #include "mfma.h"
 
 namespace ppo {
@@ -539,11 +540,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
 // loads per column in flight, exactly as gemm_finalize_kernel), writes them, and the row's NH head outputs follow as in
 // gemm_rows_kernel (lane-strided fma chain, xor-shuffle reduction, lane j finishes column j): bit-identical to the
 // two launches it replaces, one launch boundary and one round trip of h less.
-template <int KPL>
+// NA > 0: the action step of the rollout (policy_act.h) runs on the finished head row too - the row sits in the wave's
+// lanes, every lane runs the same per-sample body on broadcast values and lane 0 stores (one launch less per env step
+// and group: the sampling launch was 12 us of latency for 128 x 6 logits).
+struct ActTail {
+    float temperature;
+    uint64_t seed, offset;
+    ActOut out;
+};
+
+template <int KPL, int NA>
 __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__restrict__ partial, int split, int M, int H,
                                                             const float *__restrict__ bias, float *__restrict__ h,
                                                             const float *__restrict__ Wh, const float *__restrict__ bh, int NH,
-                                                            int relu_h, float *__restrict__ heads)
+                                                            int relu_h, float *__restrict__ heads, ActTail act)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -598,6 +608,17 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     if (lane < NH) {
         if (bh) out += bh[lane];
         heads[m * NH + lane] = out;
+    }
+    if constexpr (NA > 0) {
+        // raw logits and recorded values: each lane stores its own column (a lane-0 store loop would read the other
+        // lanes from inside a divergent branch); the per-sample body then only broadcasts logits in uniform control flow
+        if (act.out.raw_policy && lane < NA) act.out.raw_policy[(size_t)m * NA + lane] = out;
+        if (act.out.values && lane >= NA && lane < NA + act.out.vh) act.out.values[(size_t)m * act.out.vh + lane - NA] = out;
+        ActOut o = act.out;
+        o.raw_policy = nullptr;
+        o.values = nullptr;
+        policy_act_row<NA>([&](int i) { return __shfl(out, i, 64); }, m, NA, act.temperature, nullptr, act.seed, act.offset, 0, o,
+                           lane == 0);
     }
 }
 
@@ -728,6 +749,9 @@ struct HeadsTail {
     float *heads;
     int NH, relu_h;
     bool fused;  // out: the finalize launch produced the heads too
+    const ActTail *act = nullptr;  // sample actions from the head row in the same launch (n_actions in act_n)
+    int act_n = 0;
+    bool act_fused = false;  // out
 };
 
 int gemm_dispatch(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const float *B, int64_t b_sk, int64_t b_sn,
@@ -800,9 +824,19 @@ int gemm_dispatch(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const 
     if (rc) return rc;
     if (split > 1) {
         if (tail && !mask && ldc == N && N <= 256 && tail->NH <= 16 && (int64_t)split * M * N * 4 < (int64_t)kBufferBytes) {
-            hipLaunchKernelGGL((finalize_heads_kernel<4>), dim3((M + 3) / 4), dim3(256), 0, st,
-                               static_cast<const float *>(workspace), split, M, N, bias, C, tail->Wh, tail->bh, tail->NH,
-                               tail->relu_h, tail->heads);
+#define PPO_FINALIZE(NA, ACT)                                                                                          \
+    hipLaunchKernelGGL((finalize_heads_kernel<4, NA>), dim3((M + 3) / 4), dim3(256), 0, st,                            \
+                       static_cast<const float *>(workspace), split, M, N, bias, C, tail->Wh, tail->bh, tail->NH,      \
+                       tail->relu_h, tail->heads, ACT)
+            tail->act_fused = tail->act != nullptr;
+            switch (tail->act ? tail->act_n : 0) {  // the action counts of the benchmark suites; others sample in their own launch
+                case 4: PPO_FINALIZE(4, *tail->act); break;
+                case 6: PPO_FINALIZE(6, *tail->act); break;
+                case 15: PPO_FINALIZE(15, *tail->act); break;
+                case 18: PPO_FINALIZE(18, *tail->act); break;
+                default: PPO_FINALIZE(0, ActTail{}); tail->act_fused = false;
+            }
+#undef PPO_FINALIZE
             tail->fused = true;
             return check_launch("finalize_heads_kernel");
         }
@@ -836,6 +870,38 @@ extern "C" int ppo_dense_heads_forward_f32(const float *x, int relu_x, const flo
     if (rc || tail.fused) return rc;
     // the dense product ran unsplit (no workspace, short K, wide layer): the heads are their own launch
     return gemm_dispatch(h, H, 1, relu_h, Wh, 1, H, 0, bh, nullptr, heads, NH, M, NH, H, nullptr, 0, stream, nullptr);
+}
+
+extern "C" int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_actions, float temperature, const float *uniform,
+                                  uint64_t seed, uint64_t offset, int greedy, float *log_policy, int32_t *actions,
+                                  float *log_pac, float *raw_policy, float *values, int n_value_heads, void *stream);
+
+extern "C" int ppo_dense_heads_act_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh,
+                                               const float *bh, int relu_h, float *h, float *heads, int M, int K, int H,
+                                               int NH, void *workspace, size_t workspace_bytes, int n_actions,
+                                               float temperature, uint64_t seed, uint64_t offset, float *log_policy,
+                                               int32_t *actions, float *log_pac, float *raw_policy, float *values,
+                                               int n_value_heads, void *stream)
+{
+    using namespace ppo;
+    if (M < 0 || K < 0 || H <= 0 || NH <= 0) return fail(PPO_E_INVALID, "ppo_dense_heads_act_forward_f32: bad dimension");
+    if (n_actions <= 0 || n_actions > kMaxActions || n_value_heads < 0 || NH < n_actions + n_value_heads)
+        return fail(PPO_E_INVALID, "ppo_dense_heads_act_forward_f32: bad head layout (n_actions=%d value heads=%d of %d)",
+                    n_actions, n_value_heads, NH);
+    if (!(temperature > 0.f)) return fail(PPO_E_INVALID, "ppo_dense_heads_act_forward_f32: temperature must be > 0");
+    if (M == 0) return PPO_OK;
+    if (!x || !W || !Wh || !h || !heads) return fail(PPO_E_INVALID, "ppo_dense_heads_act_forward_f32: null pointer");
+    const ActTail act{temperature, seed, offset, ActOut{log_policy, actions, log_pac, raw_policy, values, n_value_heads}};
+    HeadsTail tail{Wh, bh, heads, NH, relu_h, false};
+    tail.act = &act;
+    tail.act_n = n_actions;
+    int rc = gemm_dispatch(x, K, 1, relu_x, W, 1, K, 0, b, nullptr, h, H, M, H, K, workspace, workspace_bytes, stream, &tail);
+    if (rc) return rc;
+    if (!tail.fused)
+        rc = gemm_dispatch(h, H, 1, relu_h, Wh, 1, H, 0, bh, nullptr, heads, NH, M, NH, H, nullptr, 0, stream, nullptr);
+    if (rc || tail.act_fused) return rc;
+    return ppo_policy_act_f32(heads, M, NH, n_actions, temperature, nullptr, seed, offset, 0, log_policy, actions, log_pac,
+                              raw_policy, values, n_value_heads, stream);
 }
 
 extern "C" int ppo_heads_backward_f32(const float *dheads, const float *hin, int relu_in, const float *gate, const float *Wh,

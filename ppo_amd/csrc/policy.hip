@@ -15,79 +15,22 @@
 // leading dimension ldo; columns past n_actions + vh get zero gradient (the reference's
 // advantage head is evaluated but never enters the loss, rl/models.py:506).
 #include "common.h"
+#include "policy_act.h"
 
 namespace ppo {
 namespace {
-
-constexpr int kMaxActions = 32;
-
-// counter-based uniform in (0, 1): 2 rounds of a 64-bit mix (splitmix64 finaliser) of
-// (seed, counter); 24 mantissa bits, never 0 or 1 so that log(-log u) is finite.
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t counter)
-{
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
-}
 
 // NA: the action count at compile time (0 = any): the per-action loops unroll, the row's loads are issued together and
 // the arrays stay in registers (the runtime-count form paid one L2 round trip per action and indexed a scratch array)
 template <int NA>
 __global__ __launch_bounds__(64) void policy_act_kernel(const float *__restrict__ heads, int B, int ldo, int nA_,
                                                         float temperature, const float *__restrict__ uniform,
-                                                        uint64_t seed, uint64_t offset, int greedy,
-                                                        float *__restrict__ log_policy, int32_t *__restrict__ actions,
-                                                        float *__restrict__ log_pac, float *__restrict__ raw_policy,
-                                                        float *__restrict__ values, int vh)
+                                                        uint64_t seed, uint64_t offset, int greedy, ActOut out)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int nA = NA ? NA : nA_;
-    constexpr int kUnroll = NA ? 32 : 1;  // full unroll when the count is a constant
     const float *z = heads + (size_t)b * ldo;
-    if (raw_policy)
-#pragma unroll kUnroll
-        for (int a = 0; a < nA; ++a) raw_policy[(size_t)b * nA + a] = z[a];
-    if (values)
-        for (int i = 0; i < vh; ++i) values[(size_t)b * vh + i] = z[nA + i];
-    float logits[NA ? NA : kMaxActions];
-    float mx = -INFINITY;
-#pragma unroll kUnroll
-    for (int a = 0; a < nA; ++a) {
-        logits[a] = z[a] / temperature;
-        mx = fmaxf(mx, logits[a]);
-    }
-    float se = 0.f;
-#pragma unroll kUnroll
-    for (int a = 0; a < nA; ++a) se += expf(logits[a] - mx);
-    const float lse = mx + logf(se);
-    int best = 0;
-    float best_score = -INFINITY, best_lp = 0.f;
-    bool any = false;  // no score beat -inf (NaN logits): action 0, as the running-maximum form
-#pragma unroll kUnroll
-    for (int a = 0; a < nA; ++a) {
-        const float lp = logits[a] - lse;
-        logits[a] = lp;
-        if (log_policy) log_policy[(size_t)b * nA + a] = lp;
-        float score;
-        if (greedy) {
-            score = z[a];  // argmax of the unscaled logits (rl/models.py:479)
-        } else {
-            const float u = uniform ? uniform[(size_t)b * nA + a] : uniform01(seed, offset + (uint64_t)b * nA + a);
-            score = lp - logf(-logf(u));
-        }
-        if (score > best_score) {  // first maximum wins, as np.argmax / torch.argmax
-            best_score = score;
-            best = a;
-            best_lp = lp;
-            any = true;
-        }
-    }
-    if (!any) best_lp = logits[0];
-    if (actions) actions[b] = best;
-    if (log_pac) log_pac[b] = best_lp;
+    policy_act_row<NA>([&](int i) { return z[i]; }, b, nA_, temperature, uniform, seed, offset, greedy, out, true);
 }
 
 // statistics row per sample (reduced on demand by the host side, one D2H per iteration)
@@ -187,11 +130,11 @@ extern "C" int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_acti
     if (B == 0) return PPO_OK;
     if (!heads) return fail(PPO_E_INVALID, "ppo_policy_act_f32: null heads");
     if (!(temperature > 0.f)) return fail(PPO_E_INVALID, "ppo_policy_act_f32: temperature must be > 0 (use greedy=1 for argmax)");
+    const ActOut out{log_policy, actions, log_pac, raw_policy, values, n_value_heads};
 #define PPO_ACT_CASE(NA)                                                                                              \
     case NA:                                                                                                          \
         hipLaunchKernelGGL((policy_act_kernel<NA>), dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo, \
-                           n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac,      \
-                           raw_policy, values, n_value_heads);                                                        \
+                           n_actions, temperature, uniform, seed, offset, greedy, out);                               \
         break;
     switch (n_actions) {  // the action counts of the benchmark suites at compile time, anything else at run time
         PPO_ACT_CASE(4)
@@ -200,8 +143,7 @@ extern "C" int ppo_policy_act_f32(const float *heads, int B, int ldo, int n_acti
         PPO_ACT_CASE(18)
         default:
             hipLaunchKernelGGL((policy_act_kernel<0>), dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), heads, B, ldo,
-                               n_actions, temperature, uniform, seed, offset, greedy, log_policy, actions, log_pac,
-                               raw_policy, values, n_value_heads);
+                               n_actions, temperature, uniform, seed, offset, greedy, out);
     }
 #undef PPO_ACT_CASE
     return check_launch("policy_act_kernel");

@@ -32,6 +32,26 @@ inline uint64_t mix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
+// dst[8 i .. 8 i + 7] = mix64(key + (i + 1) * golden), i = 0 .. : the observation stream of one env step.  The words are
+// independent, so the loop vectorises; the library is built once and runs on whatever host the GPU box has, hence one
+// clone per vector ISA picked at load time (AVX-512DQ has the 64-bit multiply; AVX2 builds it from 32-bit ones).  Same
+// integer arithmetic in every clone: the bytes do not depend on the host.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target_clones("avx512dq", "avx2", "default")))
+#endif
+void fill_words(uint8_t *__restrict__ dst, int64_t n_bytes, uint64_t key)
+{
+    const int64_t n8 = n_bytes / 8;
+    for (int64_t i = 0; i < n8; ++i) {
+        const uint64_t v = mix64(key + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull);
+        std::memcpy(dst + i * 8, &v, 8);
+    }
+    if (n_bytes % 8) {
+        const uint64_t v = mix64(key + (uint64_t)(n8 + 1) * 0x9E3779B97F4A7C15ull);
+        std::memcpy(dst + n8 * 8, &v, (size_t)(n_bytes % 8));
+    }
+}
+
 struct SynthEnv {
     int n_envs;
     int64_t obs_bytes;
@@ -68,19 +88,7 @@ struct SynthEnv {
     {
         // 8 bytes per mix of (seed, env, step, word)
         const uint64_t key = mix64(seed ^ mix64((uint64_t)(env_offset + e) * 0x9E3779B97F4A7C15ull + (uint64_t)steps[e]));
-        uint8_t *dst = obs + (int64_t)e * obs_bytes;
-        const int64_t n8 = obs_bytes / 8;
-        uint64_t ctr = key;
-        for (int64_t i = 0; i < n8; ++i) {
-            ctr += 0x9E3779B97F4A7C15ull;
-            const uint64_t v = mix64(ctr);
-            std::memcpy(dst + i * 8, &v, 8);
-        }
-        if (obs_bytes % 8) {
-            ctr += 0x9E3779B97F4A7C15ull;
-            const uint64_t v = mix64(ctr);
-            std::memcpy(dst + n8 * 8, &v, (size_t)(obs_bytes % 8));
-        }
+        fill_words(obs + (int64_t)e * obs_bytes, obs_bytes, key);
     }
 
     void run_range(int lo, int hi)

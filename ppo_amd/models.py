@@ -56,13 +56,14 @@ FUSE_STACK_TAIL = int(os.environ.get("PPO_AMD_FUSE_STACK_TAIL", "1"))
 FUSE_STACK_FULL = int(os.environ.get("PPO_AMD_FUSE_STACK_FULL", "1"))
 # ... with the previous stack's residual blocks chained in front of it (that stack's output stays in LDS).
 FUSE_STACK_CHAIN = int(os.environ.get("PPO_AMD_FUSE_STACK_CHAIN", "1"))
-# inference batches of at most CHAIN_SPLIT_MAX_BATCH images (a rollout group) can run the chained launch with every image
+# inference batches of at most CHAIN_SPLIT_MAX_BATCH images (a rollout group) run the chained launch with every image
 # on TWO workgroups (output channels split, halves exchanged per layer): same bits, the whole chip instead of half of it.
-# OFF by default.  Measured: alone, a 128-image forward takes 0.258 ms against 0.282 (the launch 104 us against 128);
-# inside the two-group rollout it changes nothing (0.496 against 0.493 ms per env step): the GPU is 98 % busy there,
-# the idle half of the chip under the one-workgroup-per-image launch is where the OTHER group's kernels run, and the
-# split launch spends 1.6 x the CU time (256 CUs x 104 us against 128 x 128) - it trades throughput for latency.
-CHAIN_SPLIT = int(os.environ.get("PPO_AMD_CHAIN_SPLIT", "0"))
+# Alone, a 128-image forward takes 0.258 ms against 0.282 (the launch 104 us against 128).  In the two-group rollout an
+# env step is one group's forward latency plus its host leg, so the shorter launch pays even though it spends 1.6 x
+# the CU time: variants alternated rollout by rollout in one process (tools/rollout_ab.py; separate processes differ by
+# more than the effect) 0.4846 -> 0.4649 ms per env step, 0.4584 with the action step inside the heads launch as well.
+# A partner that never arrives sets an error word which the Runner checks after every rollout (chain_split_error).
+CHAIN_SPLIT = int(os.environ.get("PPO_AMD_CHAIN_SPLIT", "1"))
 CHAIN_SPLIT_MAX_BATCH = int(os.environ.get("PPO_AMD_CHAIN_SPLIT_MAX_BATCH", "128"))
 # ... and its backward-data pass (blocks + max-pool backward + transposed first convolution) likewise.  Off by default:
 # bit-identical, but 1.445 ms per 256-sample step against 1.395 without it — it holds a whole CU's LDS, so the
@@ -327,6 +328,9 @@ class DualHeadNet:
         self._build_parameters(head_scale)
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._rec = None   # launch recorder (see encode)
+        # (n_actions, temperature, seed, offset, log_policy, actions, log_pac, raw_policy, values, n_value_heads) of
+        # ppo_dense_heads_act_forward_f32, set by the caller of an inference encode(); None again once a launch took it
+        self.act_tail = None
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
@@ -558,7 +562,12 @@ class DualHeadNet:
             calls, acts, x_slots = plan
             st, xp = _lib.current_stream(), x.data_ptr()
             for k, (fn, fn_name, args) in enumerate(calls):
-                rc = fn(xp, *args[1:], st) if k in x_slots else fn(*args, st)
+                if self.act_tail is not None and fn_name == "ppo_dense_heads_forward_f32":
+                    # the rollout's action step rides on the dense + heads launch (Runner._policy_step set the tail)
+                    fn_name, tail, self.act_tail = "ppo_dense_heads_act_forward_f32", self.act_tail, None
+                    rc = self.lib.ppo_dense_heads_act_forward_f32(*args, *tail, st)
+                else:
+                    rc = fn(xp, *args[1:], st) if k in x_slots else fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, fn_name)
             out = dict(acts)
@@ -752,8 +761,21 @@ class DualHeadNet:
             w = self.params["encoder.dense.weight"]
             ws_bytes = self.lib.ppo_gemm_workspace_bytes(B, sp.hidden_units, sp.flat)
             ws = self._ws("gemm_ws" + tag, ws_bytes)
-            self._call("ppo_dense_heads_forward_f32", _p(flat), 1, _p(w), _p(self.params["encoder.dense.bias"]), _p(self.w_heads),
-                       _p(self.b_heads), 1, _p(h), _p(o), B, sp.flat, sp.hidden_units, self.nh, _p(ws), ws_bytes)
+            args = (_p(flat), 1, _p(w), _p(self.params["encoder.dense.bias"]), _p(self.w_heads), _p(self.b_heads), 1, _p(h),
+                    _p(o), B, sp.flat, sp.hidden_units, self.nh, _p(ws), ws_bytes)
+            if self.act_tail is not None and not train:
+                # with the rollout's action step (see encode); the recorded launch list keeps the plain form, whose
+                # replay adds the tail of its own env step
+                tail, self.act_tail = self.act_tail, None
+                rec, self._rec = self._rec, None
+                try:
+                    self._call("ppo_dense_heads_act_forward_f32", *args, *tail)
+                finally:
+                    self._rec = rec
+                if rec is not None:
+                    rec.append((self.lib.ppo_dense_heads_forward_f32, "ppo_dense_heads_forward_f32", args))
+            else:
+                self._call("ppo_dense_heads_forward_f32", *args)
             acts["heads"] = o
         else:
             self._linear(flat, sp.flat, "encoder.dense", h, relu_x=1, tag=tag)

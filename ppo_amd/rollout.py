@@ -38,6 +38,9 @@ ROLLOUT_GRAPH = int(os.environ.get("PPO_AMD_ROLLOUT_GRAPH", "0"))
 # the synthetic env uploads a group's observations in this many pieces, each as soon as it has been generated (1: one
 # copy after the whole group has been stepped).  Measured: 0.491 / 0.474 / 0.487 / 0.524 ms per env step for 1 / 2 / 4 / 8
 UPLOAD_CHUNKS = int(os.environ.get("PPO_AMD_UPLOAD_CHUNKS", "2"))
+# discrete policies: sample the actions inside the dense + heads launch of the rollout forward (one launch less per group
+# and env step; same bits)
+FUSE_ACT = int(os.environ.get("PPO_AMD_FUSE_ACT", "1"))
 
 
 def _p(t):
@@ -338,11 +341,6 @@ class Runner:
         pol, val = self.policy_net, self.value_net
         hi = self.A if hi is None else hi
         B = hi - lo
-        if graph is not None:
-            g, _stage, hp, hv = graph
-            g.replay()
-        else:
-            hp, hv = self._forward_heads(self.all_obs[t, lo:hi], tag)
         A, nA = self.A, self.n_actions
         final = t >= self.N
         seed = self._device_seed * 1000003 + self.rank
@@ -355,8 +353,23 @@ class Runner:
             return buf.data_ptr() + first * buf.stride(1) * buf.element_size()
 
         values = None if self.dual else self.value.data_ptr() + first * self.value.stride(1) * 4
+        discrete = self.action_dist == "discrete"
+        if graph is not None:
+            g, _stage, hp, hv = graph
+            g.replay()
+        else:
+            if discrete and FUSE_ACT:
+                # the sampling rides on the policy net's dense + heads launch when that forward replays its recorded
+                # launch list (models.DualHeadNet.encode); otherwise the tail comes back and is launched below
+                pol.act_tail = (nA, 1.0, seed & (2**64 - 1), counter, row(self.log_policy), row(self.actions),
+                                row(self.log_pac), row(self.raw_policy), values, self.VH)
+            hp, hv = self._forward_heads(self.all_obs[t, lo:hi], tag)
+        sampled = discrete and graph is None and FUSE_ACT and pol.act_tail is None
+        pol.act_tail = None
 
-        if self.action_dist == "discrete":
+        if sampled:
+            pass
+        elif discrete:
             self._call("ppo_policy_act_f32", _p(hp), B, pol.nh, nA, 1.0, None, seed & (2**64 - 1), counter, 0,
                        row(self.log_policy), row(self.actions), row(self.log_pac), row(self.raw_policy), values, self.VH)
         else:
@@ -394,6 +407,12 @@ class Runner:
             # array-stepping groups: the synthetic env, and gym-API envs behind the process pool and its vector
             # wrappers (ppo_amd/hybrid_vec_env.py `PoolGroup`, ppo_amd/wrappers.py `parts`)
             self._rollout_pipelined(parts)
+            for net in {id(n): n for n in (self.policy_net, self.value_net)}.values():
+                if net.chain_split_error():
+                    # a workgroup of the two-workgroups-per-image launch gave up waiting for its partner's half of a
+                    # map: this rollout's head outputs cannot be trusted
+                    raise RuntimeError("the split chained launch timed out waiting for a partner workgroup "
+                                       "(PPO_AMD_CHAIN_SPLIT=0 runs one workgroup per image)")
             if hasattr(env, "finish_rollout"):
                 # what the vector wrappers do to the rewards needs every env's reward of a step at once (the running
                 # return statistics): applied here, step by step in the reference's order, once the rollout is in

@@ -268,6 +268,60 @@ def test_dense_heads_forward_is_bitwise_the_two_products(bsz):
     assert _close(o_ref, F.relu(F.relu(x) @ W.t() + b) @ Wh.t() + bh, 1e-4)
 
 
+@pytest.mark.parametrize("bsz,nA", [(128, 6), (100, 4), (1, 15), (256, 18), (37, 7)])
+@pytest.mark.parametrize("use_ws", [True, False])
+def test_dense_heads_with_action_sampling_is_bitwise_the_separate_launches(bsz, nA, use_ws):
+    """ppo_dense_heads_act_forward_f32 (the rollout's action step on the finished head row, in the finalize launch) against
+    ppo_dense_heads_forward_f32 followed by ppo_policy_act_f32 with the same (seed, offset): heads, raw logits, log-policy,
+    sampled actions, their log-probabilities and the recorded values bit for bit - for the action counts with a fused
+    form (4 / 6 / 15 / 18), one without (7: the entry point runs the separate launches itself), with and without a
+    split-K workspace (without: nothing is fused), and with NULL outputs (the rollout's last row)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(bsz * 31 + nA)
+    K, H, vh = 3872, 256, 2
+    NH = nA + vh + 3
+    x = torch.randn(bsz, K, generator=g).to(DEV)
+    W = (torch.randn(H, K, generator=g) * 0.02).to(DEV)
+    b = torch.randn(H, generator=g).to(DEV)
+    Wh = (torch.randn(NH, H, generator=g) * 0.1).to(DEV)
+    bh = torch.randn(NH, generator=g).to(DEV)
+    ws_bytes = lib.ppo_gemm_workspace_bytes(bsz, H, K) if use_ws else 0
+    ws = torch.empty(max(ws_bytes // 4, 1), device=DEV)
+    seed, offset = 0x1234567890ABCDEF, 987654321 * nA
+
+    def outputs():
+        return (torch.full((bsz, nA), float("nan"), device=DEV), torch.full((bsz,), -7, dtype=torch.int32, device=DEV),
+                torch.full((bsz,), float("nan"), device=DEV), torch.full((bsz, nA), float("nan"), device=DEV),
+                torch.full((bsz, vh), float("nan"), device=DEV))
+
+    h1, o1 = torch.empty(bsz, H, device=DEV), torch.empty(bsz, NH, device=DEV)
+    _lib.check(lib.ppo_dense_heads_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h1), _p(o1), bsz, K, H, NH,
+                                               _p(ws) if use_ws else None, ws_bytes, _st()), "dense_heads")
+    want = outputs()
+    _lib.check(lib.ppo_policy_act_f32(_p(o1), bsz, NH, nA, 1.0, None, seed, offset, 0, _p(want[0]), _p(want[1]), _p(want[2]),
+                                      _p(want[3]), _p(want[4]), vh, _st()), "act")
+    h2, o2 = torch.full_like(h1, float("nan")), torch.full_like(o1, float("nan"))
+    got = outputs()
+    _lib.check(lib.ppo_dense_heads_act_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h2), _p(o2), bsz, K, H, NH,
+                                                   _p(ws) if use_ws else None, ws_bytes, nA, 1.0, seed, offset, _p(got[0]),
+                                                   _p(got[1]), _p(got[2]), _p(got[3]), _p(got[4]), vh, _st()), "dense_heads_act")
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2) and torch.equal(o1, o2)
+    for name, a, w in zip(("log_policy", "actions", "log_pac", "raw_policy", "values"), got, want):
+        assert torch.equal(a, w), name
+    assert int(got[1].min()) >= 0 and int(got[1].max()) < nA and len(set(got[1].tolist())) > (1 if bsz > 8 else 0)
+    # last row of a rollout: only the values are recorded
+    vals = torch.full((bsz, vh), float("nan"), device=DEV)
+    _lib.check(lib.ppo_dense_heads_act_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h2), _p(o2), bsz, K, H, NH,
+                                                   _p(ws) if use_ws else None, ws_bytes, nA, 1.0, seed, offset, None, None, None,
+                                                   None, _p(vals), vh, _st()), "dense_heads_act (values only)")
+    assert torch.equal(vals, want[4])
+    # a head row too short for the action + value columns is an error
+    assert lib.ppo_dense_heads_act_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h2), _p(o2), bsz, K, H, nA,
+                                               _p(ws) if use_ws else None, ws_bytes, nA, 1.0, seed, offset, None, None, None,
+                                               None, _p(vals), vh, _st()) != 0
+
+
 @pytest.mark.parametrize("bsz,H,NH,relu", [(256, 256, 13, 1), (7, 256, 13, 1), (300, 64, 4, 0), (129, 100, 16, 1), (1, 256, 1, 0)])
 def test_heads_backward_one_launch(bsz, H, NH, relu):
     """ppo_heads_backward_f32: dh, dWh against the autograd formulas; dbh / db_next bit-identical to ppo_colsum_f32 of

@@ -1,0 +1,42 @@
+"""Interleaved A/B of rollout switches inside ONE process (run-to-run variation between processes on a GPU box is several
+per cent, more than most of these switches move): variants alternate rollout by rollout on the same Runner.
+Usage: python tools/rollout_ab.py [n_steps] [rounds]     variants: models.CHAIN_SPLIT x rollout.FUSE_ACT"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ppo_amd import envs, logger, models, rollout  # noqa: E402
+from ppo_amd.config import args  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+args.setup(["--agents=256", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala", "--env_type=synthetic",
+            "--env_embed_time=False", "--seed=1", "--device=cuda", "--policy_opt_mini_batch_size=256", "--policy_opt_epochs=2",
+            "--disable_logging=True", "--upload_batch=True", "--env_reward_normalization=off"])
+torch.manual_seed(1)
+np.random.seed(1)
+shape, nA = envs.get_env_spec()
+model = models.TVFModel("impala", input_dims=shape, actions=nA, device="cuda", architecture="single", hidden_units=256,
+                        head_scale=0.1, head_bias=True)
+r = rollout.Runner(model, logger.Logger(quiet=True))
+r.vec_env = envs.create_envs_classic()
+r.reset()
+variants = {"base": (0, 0, 0), "block": (1, 0, 0), "block+act": (1, 0, 1), "block+split": (1, 1, 0), "block+split+act": (1, 1, 1)}
+times = {k: [] for k in variants}
+for rnd in range(rounds + 1):
+    for name, (blk, split, act) in variants.items():
+        models.FUSE_BLOCK, models.CHAIN_SPLIT, rollout.FUSE_ACT = blk, split, act
+        model.policy_net._plans.clear()
+        r.generate_rollout()  # records the launch lists of this variant
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.generate_rollout()
+        torch.cuda.synchronize()
+        if rnd:
+            times[name].append((time.perf_counter() - t0) / (N + 1) * 1e3)
+for name, t in times.items():
+    print(f"{name:18s} median {np.median(t):.4f}  mean {np.mean(t):.4f}  min {np.min(t):.4f} ms per env step  ({len(t)} rollouts)")

@@ -16,7 +16,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 args.setup(["--agents=256", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala", "--env_type=synthetic",
             "--env_embed_time=False", "--seed=1", "--device=cuda", "--policy_opt_mini_batch_size=256", "--policy_opt_epochs=2",
             "--disable_logging=True", "--upload_batch=True", "--env_reward_normalization=off",
-            f"--env_synthetic_threads={os.environ.get('PPO_SYNTH_THREADS', '8')}"])
+            f"--env_synthetic_threads={os.environ.get('PPO_SYNTH_THREADS', '8')}"] + os.environ.get("PPO_EXTRA_ARGS", "").split())
 torch.manual_seed(1)
 np.random.seed(1)
 shape, nA = envs.get_env_spec()

@@ -20,8 +20,9 @@ for f in files:
 rows.sort()
 print(len(rows), "dispatches; columns:", list(csv.DictReader(open(files[0])).fieldnames))
 # an env step of one group ends with its sampling kernel
-acts = [i for i, r in enumerate(rows) if "policy_act" in r[2]]
-print("policy_act launches:", len(acts))
+step_end = "policy_act" if any("policy_act" in r[2] for r in rows) else "finalize_heads"  # sampling fused into the heads launch
+acts = [i for i, r in enumerate(rows) if step_end in r[2]]
+print(step_end, "launches:", len(acts))
 t_first = rows[acts[len(acts) // 2]][0]
 sel = [r for r in rows if r[0] >= t_first][: 60 * show]
 base = sel[0][0]
@@ -43,7 +44,7 @@ for t, d in ev:
     depth += d
     last = t
 span = half[-1][1] - half[0][0]
-n_steps = sum(1 for r in half if "policy_act" in r[2]) / 2
+n_steps = sum(1 for r in half if step_end in r[2]) / 2
 print(f"second half: span {span / 1e6:.2f} ms, busy {busy / span:.1%}, two or more kernels at once {over / span:.1%}, "
       f"{span / 1e3 / max(n_steps, 1):.1f} us per env step over {n_steps:.0f} steps")
 tot = collections.Counter()
