@@ -351,6 +351,8 @@ def _batch_of(fn, a):
         return a[15]
     if fn == "ppo_impala_stack16_forward_f32":
         return a[-4]
+    if fn == "ppo_impala_stack_chain_split_forward_f32":
+        return a[8]
     if fn in ("ppo_dense_heads_forward_f32", "ppo_dense_heads_act_forward_f32"):
         return a[9]
     if fn == "ppo_conv3x3_block_forward_packed_f32":
@@ -393,6 +395,10 @@ def _describe_call(fn, a):
                 _conv(n, c, c, h, w) + 4 * _conv(n, c, c, _half(h), _half(w)), None)
     if fn == "ppo_impala_stack_chain_forward_f32":
         n, c, h, w = a[15:19]
+        return (f"chained stacks fwd (9 conv + pool) {c}ch {h}x{w}",
+                5 * _conv(n, c, c, h, w) + 4 * _conv(n, c, c, _half(h), _half(w)), None)
+    if fn == "ppo_impala_stack_chain_split_forward_f32":  # (in, pre_w, pre_b, w, b, out, ws, ws_bytes, n, channels, h, w):
+        n, c, h, w = a[8:12]                                # the same layers, two workgroups per image (inference)
         return (f"chained stacks fwd (9 conv + pool) {c}ch {h}x{w}",
                 5 * _conv(n, c, c, h, w) + 4 * _conv(n, c, c, _half(h), _half(w)), None)
     if fn == "ppo_impala_stack_full_backward_f32":
@@ -873,8 +879,9 @@ def main():
         table = kt.table()
         out["roofline_by_kernel"] = table
         if roofline is not None:
-            # the same kernel at the ROLLOUT's geometry (half-batch env groups: one workgroup per image leaves half the
-            # CUs idle), so that the quoted fraction is not the flattering half of its launches
+            # the same layers at the ROLLOUT's geometry (half-batch env groups: 128 images for 256 CUs; run as the
+            # two-workgroups-per-image launch unless PPO_AMD_CHAIN_SPLIT=0), so that the quoted fraction is not the
+            # flattering half of their launches
             for row in table["rows"]:
                 if row["kernel"].startswith("chained stacks fwd") and "[n=" in row["kernel"] and "frac" in row:
                     roofline["rollout_geometry"] = {k_: row[k_] for k_ in ("kernel", "launches", "avg_us", "achieved", "frac")}

@@ -1,6 +1,7 @@
 """Interleaved A/B of rollout switches inside ONE process (run-to-run variation between processes on a GPU box is several
 per cent, more than most of these switches move): variants alternate rollout by rollout on the same Runner.
-Usage: python tools/rollout_ab.py [n_steps] [rounds]     variants: models.CHAIN_SPLIT x rollout.FUSE_ACT"""
+Usage: [PPO_EXTRA_ARGS="--agents=1024 ..."] python tools/rollout_ab.py [n_steps] [rounds]
+variants: models.FUSE_BLOCK, models.CHAIN_SPLIT, rollout.FUSE_ACT"""
 import os
 import sys
 import time
@@ -16,7 +17,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 args.setup(["--agents=256", f"--n_steps={N}", "--model_architecture=single", "--model_encoder=impala", "--env_type=synthetic",
             "--env_embed_time=False", "--seed=1", "--device=cuda", "--policy_opt_mini_batch_size=256", "--policy_opt_epochs=2",
-            "--disable_logging=True", "--upload_batch=True", "--env_reward_normalization=off"])
+            "--disable_logging=True", "--upload_batch=True", "--env_reward_normalization=off"]
+           + os.environ.get("PPO_EXTRA_ARGS", "").split())  # e.g. the procgen shape: --agents=1024 --env_synthetic_shape=3,64,64 ...
 torch.manual_seed(1)
 np.random.seed(1)
 shape, nA = envs.get_env_spec()
