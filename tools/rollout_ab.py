@@ -28,10 +28,19 @@ r = rollout.Runner(model, logger.Logger(quiet=True))
 r.vec_env = envs.create_envs_classic()
 r.reset()
 variants = {"base": (0, 0, 0), "block": (1, 0, 0), "block+act": (1, 0, 1), "block+split": (1, 1, 0), "block+split+act": (1, 1, 1)}
+if os.environ.get("PPO_AB") == "chunks":  # pieces a group's observations go up in (all kernel switches on)
+    variants = {f"upload chunks {c}": (1, 1, 1, c) for c in (1, 2, 4, 8)}
+if os.environ.get("PPO_AB") == "graph":  # hipGraph of a group's forward (fixed staging buffer, separate sampling launch)
+    variants = {"eager": (1, 1, 1, 2, 0), "graph": (1, 1, 1, 2, 1)}
 times = {k: [] for k in variants}
 for rnd in range(rounds + 1):
-    for name, (blk, split, act) in variants.items():
+    for name, (blk, split, act, *rest) in variants.items():
         models.FUSE_BLOCK, models.CHAIN_SPLIT, rollout.FUSE_ACT = blk, split, act
+        if rest:
+            rollout.UPLOAD_CHUNKS = rest[0]
+        if len(rest) > 1:
+            rollout.ROLLOUT_GRAPH = rest[1]
+            r._graphs.clear()
         model.policy_net._plans.clear()
         r.generate_rollout()  # records the launch lists of this variant
         torch.cuda.synchronize()
