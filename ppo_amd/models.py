@@ -331,6 +331,7 @@ class DualHeadNet:
         # (n_actions, temperature, seed, offset, log_policy, actions, log_pac, raw_policy, values, n_value_heads) of
         # ppo_dense_heads_act_forward_f32, set by the caller of an inference encode(); None again once a launch took it
         self.act_tail = None
+        self._chain_split_usable = None  # decided at the first split launch (see _encode_impala)
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
@@ -682,15 +683,38 @@ class DualHeadNet:
                 a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
                 outs = (_p(p) if train else None, _p(idx), _p(a0) if train else None, _p(q0) if train else None,
                         _p(a1) if train else None, _p(q1), B, cout, h, w)
-                if pending is not None and not train and CHAIN_SPLIT and B <= CHAIN_SPLIT_MAX_BATCH \
-                        and (cout, h, w) == (32, 21, 21):
+                if pending is not None and not train and CHAIN_SPLIT and self._chain_split_usable is not False \
+                        and B <= CHAIN_SPLIT_MAX_BATCH and (cout, h, w) == (32, 21, 21):
                     # a rollout group (at most half as many images as CUs): every image on two workgroups that split
                     # the output channels of the 21x21 convolutions and exchange halves (bit-identical, ~0.7 x the time)
                     p_prev, ptrs_prev, _saves = pending
                     pending = None
                     ws = self._chain_split_ws(tag, B, cout, h, w)
-                    self._call("ppo_impala_stack_chain_split_forward_f32", _p(p_prev), ptrs_prev[0], ptrs_prev[1],
-                               full[0], full[1], _p(q1), _p(ws), ws.numel(), B, cout, h, w)
+                    split_args = (_p(p_prev), ptrs_prev[0], ptrs_prev[1], full[0], full[1], _p(q1), _p(ws), ws.numel(),
+                                  B, cout, h, w)
+                    chain_args = (_p(p_prev), ptrs_prev[0], ptrs_prev[1], None, None, None, None, full[0], full[1], *outs)
+                    if self._chain_split_usable is None:
+                        # First use on this device: the exchange goes through the L2 the two workgroups of a pair share,
+                        # which rests on workgroups b and b ^ 8 landing on one XCD.  Both forms once on this batch; if
+                        # the bits differ (another partition mode, another dispatch order) the one-workgroup form stays.
+                        rec, self._rec = self._rec, None
+                        try:
+                            self._call("ppo_impala_stack_chain_split_forward_f32", *split_args)
+                            got = q1.clone()
+                            self._call("ppo_impala_stack_chain_forward_f32", *chain_args)
+                            self._chain_split_usable = bool(torch.equal(got, q1)) and not self.chain_split_error()
+                        finally:
+                            self._rec = rec
+                        if not self._chain_split_usable:
+                            import warnings
+                            warnings.warn("the two-workgroups-per-image chain launch does not reproduce the one-workgroup "
+                                          "launch on this device; using the latter (PPO_AMD_CHAIN_SPLIT=0 silences this)")
+                        if rec is not None:  # the recorded launch list gets the form that was chosen (q1 holds its result)
+                            name = "ppo_impala_stack_chain_split_forward_f32" if self._chain_split_usable \
+                                else "ppo_impala_stack_chain_forward_f32"
+                            rec.append((getattr(self.lib, name), name, split_args if self._chain_split_usable else chain_args))
+                    elif self._chain_split_usable:
+                        self._call("ppo_impala_stack_chain_split_forward_f32", *split_args)
                 elif pending is not None:
                     # the previous stack's blocks run inside the same launch, on its pooled map
                     p_prev, ptrs_prev, (pa0, pq0, pa1, pq1) = pending

@@ -430,7 +430,8 @@ def test_two_workgroups_per_image_chain_launch_is_bit_identical(gold, monkeypatc
     TWO workgroups that split the output channels and exchange halves per layer (stack_chain_split_kernel).  Same K
     order and epilogue arithmetic per output element, so the heads must be bit-identical to the one-workgroup-per-image
     launch - over repeated launches (the kernel advances its own launch counter), for batches that do not fill the
-    pairing groups of 8, and with no partner ever missing."""
+    pairing groups of 8, and with no partner ever missing.  (The net's own first-use check of the split form - it keeps
+    the one-workgroup launch if the bits differ - must have passed.)"""
     g, meta = gold
     rng = np.random.default_rng(B)
     x = torch.from_numpy(rng.integers(0, 256, size=(B, *meta["input_dims"]), dtype=np.uint8)).cuda()
@@ -449,6 +450,9 @@ def test_two_workgroups_per_image_chain_launch_is_bit_identical(gold, monkeypatc
         torch.cuda.synchronize()
         assert ("ppo_impala_stack_chain_split_forward_f32" in calls) == bool(split)
         assert not net.chain_split_error()
+        # the first split launch checks itself against the one-workgroup form and would fall back on a mismatch:
+        # on this hardware it must not have
+        assert net._chain_split_usable is (True if split else None)
         outs[split] = res
     for (p0, v0), (p1, v1) in zip(outs[0], outs[1]):
         assert torch.equal(p0, p1) and torch.equal(v0, v1)
