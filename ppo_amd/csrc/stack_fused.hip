@@ -926,9 +926,10 @@ struct ChainSplitArgs {
     float *out;              // q1 [n, C, HO, WO]
     float *xbuf;             // [n][2][C][HI * WI] exchange slots
     uint32_t *flags;         // [n][2]
-    uint32_t *ctl;           // launch number, workgroups done, error
+    uint32_t *ctl;           // launch number, workgroups done, error, fault injection (tests: see the kernel)
     int n_images;
-    int skip;                // timing aid (PPO_AMD_SPLIT_SKIP): 1 no waiting for the partner, 2 no 11x11 part - garbage out
+    int skip;                // timing aid, PPO_TUNE_TIMING_AIDS builds only (PPO_AMD_SPLIT_SKIP): 1 no waiting for the
+                             // partner, 2 no 11x11 part - garbage out; always 0 in the shipped library
 };
 
 constexpr int kSplitWaves = 8;  // 28 pixel tiles of the 21x21 map, four per wave (the eighth wave's are past the map); one
@@ -959,6 +960,11 @@ __global__ __launch_bounds__(kSplitWaves * 64) void stack_chain_split_kernel(Cha
     lane_map_init<HO, WO, SO::PLANE, SO::G, MTO>(lmo, wave & 3, l15, g);
 
     const uint32_t base = __hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u;  // 5 exchanges per launch
+    // ctl[3] != 0 (set by tests only, DualHeadNet.chain_split_inject_fault): the second workgroup of every pair withholds
+    // its flags and the spin gives up early - the path a partner that never arrives takes, driven on purpose
+    const uint32_t fault = __hip_atomic_load(a.ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t spin_limit = fault ? 1u << 10 : kSpinLimit;
+    bool gave_up = false;  // thread 0's: after one timeout this workgroup no longer waits (its results are garbage anyway)
     zero_lds<SI::LDS_MAP, THREADS>(smem + B_OFF, tid);  // halo rows / guards of the second big map
 
     for (int img = pair0; img < a.n_images; img += n_pairs) {
@@ -975,11 +981,18 @@ __global__ __launch_bounds__(kSplitWaves * 64) void stack_chain_split_kernel(Cha
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_store(flag_own, base + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(fault && h == 1))
+                    __hip_atomic_store(flag_own, base + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t it = 0;
-                while (!(a.skip & 1) && __hip_atomic_load(flag_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + step) {
-                    if (++it > kSpinLimit) {  // the partner never came: say so and go on (garbage, but the device lives)
+                while (!(a.skip & 1) && !gave_up &&
+                       __hip_atomic_load(flag_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + step) {
+                    // the partner never came: say so and go on (garbage, but the device lives).  Somebody else's timeout
+                    // (looked at every 1024 polls) ends this wait too: the launch's results are void already, so the whole
+                    // launch costs one spin limit, not one per exchange and image
+                    if (++it > spin_limit ||
+                        ((it & 1023u) == 0 && __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                         __hip_atomic_store(a.ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gave_up = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
@@ -1329,7 +1342,11 @@ extern "C" int ppo_impala_stack_chain_split_forward_f32(const float *in, const f
     args.flags = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + slots);
     args.ctl = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + slots + flags);
     args.n_images = n_images;
+#ifdef PPO_TUNE_TIMING_AIDS  // tools/build_variant.sh builds only: the shipped library has no switch that voids results
     static const int skip = getenv("PPO_AMD_SPLIT_SKIP") ? atoi(getenv("PPO_AMD_SPLIT_SKIP")) : 0;
     args.skip = skip;
+#else
+    args.skip = 0;
+#endif
     return launch_chain_split<32, 21, 21, 11, 11>(args, as_stream(stream));
 }

@@ -142,7 +142,7 @@ struct alignas(16) MainRec {  // everything a term needs as ready-made LDS byte 
     int32_t mode, pad0, pad1, pad2;
 };
 struct alignas(8) LaneRec {  // the same, 24 bytes: kept in vector registers, one record per lane (see the kernel)
-    uint32_t a;  // off_sd | thr << 16
+    uint32_t a;  // off_sd / 8 | thr << 16   (off_sd / 8 = nd * T < 20480 and thr <= N < 40960 while the column fits in LDS)
     uint32_t b;  // off_v | mode << 24            (lim = off_v + thr * VS * 4)
     double w0, w1;
 };
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void tvf_pack_kernel(const int32_t *__restrict
         r.w0 = main_w[2 * i], r.w1 = main_w[2 * i + 1];
         mrec[i] = r;
         LaneRec l;
-        l.a = (uint32_t)r.off_sd | (uint32_t)r.thr << 16;
+        l.a = (uint32_t)(r.off_sd >> 3) | (uint32_t)r.thr << 16;
         l.b = (uint32_t)r.off_v | (uint32_t)r.mode << 24;
         l.w0 = r.w0, l.w1 = r.w1;
         lrec[i] = l;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kColumnThreads) void tvf_column_kernel(
                             w1l = __builtin_amdgcn_readlane(rw1l[s2], ln), w1h = __builtin_amdgcn_readlane(rw1h[s2], ln);
                         }
                     }
-                    r.off_sd = (int32_t)(a & 0xffffu);
+                    r.off_sd = (int32_t)((a & 0xffffu) << 3);
                     r.thr = (int32_t)(a >> 16);
                     r.off_v = (int32_t)(b & 0xffffffu);
                     r.mode = (int32_t)(b >> 24);
@@ -509,8 +509,13 @@ int launch_column(const ColumnLds &L, hipStream_t st, const float *rewards, cons
                   const uint8_t *k_zero, float *out, ColumnArgs args)
 {
     auto kern = tvf_column_kernel<MAXR>;
-    // timing aid (tools/tvf_phases.sh): bit 0 skips the walk, 1 the terms, 2 the stores - results are then garbage
+    // timing aid (tools/tvf_phases.sh, a -DPPO_TUNE_TIMING_AIDS build): bit 0 skips the walk, 1 the terms, 2 the stores -
+    // results are then garbage; the shipped library has no such switch
+#ifdef PPO_TUNE_TIMING_AIDS
     static const int skip = getenv("PPO_AMD_TVF_SKIP") ? atoi(getenv("PPO_AMD_TVF_SKIP")) : 0;
+#else
+    constexpr int skip = 0;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -565,6 +570,9 @@ extern "C" int ppo_tvf_returns_f32(const float *rewards, const uint8_t *dones, c
         for (int T = 64; T >= 16; T >>= 1) {
             const ColumnLds L = column_lds(N, V, K, ND, max_n, T);
             if (L.bytes > kLdsLimit) continue;
+            // the lane-resident plan records hold nd * T and N - n in 16 bits each; a column that fits in LDS is far
+            // inside both (sd alone would be 512 KB, vals 256 KB) - refuse rather than wrap if that ever changes
+            if ((size_t)ND * T >= 65536 || N >= 65536) break;
             ColumnArgs ca{};
             ca.gamma = gamma;
             ca.N = N, ca.A = A, ca.V = V, ca.K = K, ca.C = C, ca.ND = ND, ca.max_n = max_n;

@@ -62,7 +62,10 @@ FUSE_STACK_CHAIN = int(os.environ.get("PPO_AMD_FUSE_STACK_CHAIN", "1"))
 # env step is one group's forward latency plus its host leg, so the shorter launch pays even though it spends 1.6 x
 # the CU time: variants alternated rollout by rollout in one process (tools/rollout_ab.py; separate processes differ by
 # more than the effect) 0.4846 -> 0.4649 ms per env step, 0.4584 with the action step inside the heads launch as well.
-# A partner that never arrives sets an error word which the Runner checks after every rollout (chain_split_error).
+# A partner that never arrives sets an error word which the Runner checks after every rollout (chain_split_error) and
+# answers by dropping to the one-workgroup launch and redoing the rollout (Runner.generate_rollout).  Only a forward made
+# under `net.allow_chain_split` (the Runner's pipelined rollout sets it, and checks) takes the split launch: evaluation,
+# greedy and generic-rollout forwards, whose callers never look at the error word, keep the one-workgroup launch.
 CHAIN_SPLIT = int(os.environ.get("PPO_AMD_CHAIN_SPLIT", "1"))
 CHAIN_SPLIT_MAX_BATCH = int(os.environ.get("PPO_AMD_CHAIN_SPLIT_MAX_BATCH", "128"))
 # ... and its backward-data pass (blocks + max-pool backward + transposed first convolution) likewise.  Off by default:
@@ -332,6 +335,7 @@ class DualHeadNet:
         # ppo_dense_heads_act_forward_f32, set by the caller of an inference encode(); None again once a launch took it
         self.act_tail = None
         self._chain_split_usable = None  # decided at the first split launch (see _encode_impala)
+        self.allow_chain_split = False   # set by a caller that checks chain_split_error() afterwards
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
@@ -557,7 +561,7 @@ class DualHeadNet:
         # recorded launch list: every pointer and size of a (tag, batch) forward is fixed — scratch buffers
         # persist, parameters are views of one flat buffer — except the input, which is patched in.  That cuts
         # the per-launch Python work to the ctypes call itself.
-        key = (tag, x.shape[0], x.dtype)
+        key = (tag, x.shape[0], x.dtype, self.allow_chain_split)
         plan = None if train or not self.use_plans else self._plans.get(key)
         if plan is not None:
             calls, acts, x_slots = plan
@@ -661,11 +665,31 @@ class DualHeadNet:
         return ws
 
     def chain_split_error(self) -> bool:
-        """True if any split launch saw a workgroup whose partner never arrived (word 2 of the control words)."""
-        bad = False
+        """True if any split launch saw a workgroup whose partner never arrived (word 2 of the control words).
+        One device -> host copy however many workspaces there are."""
+        if not self._split_ws:
+            return False
+        words = torch.stack([ws[-16:].view(torch.int32)[2] for ws in self._split_ws.values()])
+        return bool(words.any().item())
+
+    def chain_split_armed(self) -> bool:
+        """Whether a forward under allow_chain_split may take the split launch (so its caller has to check for errors)."""
+        return bool(CHAIN_SPLIT) and self.encoder_kind == "impala" and self._chain_split_usable is not False
+
+    def chain_split_disable(self):
+        """After an error: the one-workgroup launch from now on.  Clears the error (and fault-injection) words and
+        forgets every recorded launch list that holds the split launch."""
+        self._chain_split_usable = False
         for ws in self._split_ws.values():
-            bad |= bool(ws[-16:].view(torch.int32)[2].item())
-        return bad
+            ws[-16:].view(torch.int32)[2:4].zero_()
+        self._plans = {k: v for k, v in self._plans.items()
+                       if all(name != "ppo_impala_stack_chain_split_forward_f32" for _f, name, _a in v[0])}
+
+    def chain_split_inject_fault(self):
+        """Tests only: from the next split launch on, the second workgroup of every pair withholds its flags (control
+        word 3, csrc/stack_fused.hip), i.e. the first one times out exactly as if its partner had never been dispatched."""
+        for ws in self._split_ws.values():
+            ws[-16:].view(torch.int32)[3] = 1
 
     def _encode_impala(self, x, train, tag):
         sp = self.spec
@@ -683,8 +707,8 @@ class DualHeadNet:
                 a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
                 outs = (_p(p) if train else None, _p(idx), _p(a0) if train else None, _p(q0) if train else None,
                         _p(a1) if train else None, _p(q1), B, cout, h, w)
-                if pending is not None and not train and CHAIN_SPLIT and self._chain_split_usable is not False \
-                        and B <= CHAIN_SPLIT_MAX_BATCH and (cout, h, w) == (32, 21, 21):
+                if pending is not None and not train and CHAIN_SPLIT and self.allow_chain_split \
+                        and self._chain_split_usable is not False and B <= CHAIN_SPLIT_MAX_BATCH and (cout, h, w) == (32, 21, 21):
                     # a rollout group (at most half as many images as CUs): every image on two workgroups that split
                     # the output channels of the 21x21 convolutions and exchange halves (bit-identical, ~0.7 x the time)
                     p_prev, ptrs_prev, _saves = pending

@@ -19,6 +19,7 @@ What changed relative to the reference, and why (MI355X-first):
     RCCL all-reduce of the flat gradient per optimiser step and one of the three advantage moments per
     batch, so an N-GPU run equals a 1-GPU run with N*A envs up to minibatch composition.
 """
+import copy
 import math
 import os
 
@@ -159,6 +160,11 @@ class Runner:
         self.timers = {}
         self._reducers = {}
         if self.world > 1:
+            # one base seed for all ranks (the rank is mixed in where draws are made): an unseeded run would otherwise
+            # checkpoint rank 0's draw and hand it to every rank on resume, i.e. switch the other ranks' streams
+            seed_t = torch.tensor([self._device_seed], dtype=torch.int64, device=dev)
+            parallel.broadcast_(seed_t)
+            self._device_seed = int(seed_t.item())
             self.sync_replicas()
             for net in {id(n): n for n in (self.policy_net, self.value_net)}.values():
                 red = parallel.GradReducer(net.grad, net.early_grad_offset)
@@ -389,6 +395,9 @@ class Runner:
             if t is not None:
                 self._finished_lengths[t].extend(int(x) for x in np.asarray(ep_len)[finished])
             for s, l in zip(ep_score[finished][:8], ep_len[finished][:8]):
+                if getattr(self, "_pending_episodes", None) is not None:
+                    self._pending_episodes.append((s, l))  # logged once the rollout stands (generate_rollout)
+                    continue
                 self.log.watch_full("ep_score", s, history_length=100)
                 self.log.watch_full("ep_length", l, history_length=100)
 
@@ -406,13 +415,19 @@ class Runner:
         if not self.force_generic_rollout and all(hasattr(p, "step_arrays") for p in parts):
             # array-stepping groups: the synthetic env, and gym-API envs behind the process pool and its vector
             # wrappers (ppo_amd/hybrid_vec_env.py `PoolGroup`, ppo_amd/wrappers.py `parts`)
-            self._rollout_pipelined(parts)
-            for net in {id(n): n for n in (self.policy_net, self.value_net)}.values():
-                if net.chain_split_error():
-                    # a workgroup of the two-workgroups-per-image launch gave up waiting for its partner's half of a
-                    # map: this rollout's head outputs cannot be trusted
-                    raise RuntimeError("the split chained launch timed out waiting for a partner workgroup "
-                                       "(PPO_AMD_CHAIN_SPLIT=0 runs one workgroup per image)")
+            nets = list({id(n): n for n in (self.policy_net, self.value_net)}.values())
+            armed = [n for n in nets if n.chain_split_armed()]
+            # the two-workgroups-per-image launch (models.CHAIN_SPLIT) can, in principle, time out waiting for a partner
+            # workgroup; its results are then void.  An env that can be put back exactly is, and the rollout is redone
+            snap = self._rollout_snapshot(env) if armed and getattr(env, "exact_snapshot", False) else None
+            self._pending_episodes = []
+            self._rollout_pipelined(parts, armed)
+            if armed and any(n.chain_split_error() for n in armed):
+                self._chain_split_failed(armed, env, snap, parts)
+            for s_, l_ in self._pending_episodes:
+                self.log.watch_full("ep_score", s_, history_length=100)
+                self.log.watch_full("ep_length", l_, history_length=100)
+            self._pending_episodes = None
             if hasattr(env, "finish_rollout"):
                 # what the vector wrappers do to the rewards needs every env's reward of a step at once (the running
                 # return statistics): applied here, step by step in the reference's order, once the rollout is in
@@ -426,7 +441,64 @@ class Runner:
         self._sample_calls += N + 1
         self.step += N * A * self.world
 
-    def _rollout_pipelined(self, parts):
+    def _rollout_snapshot(self, env):
+        """Everything a pipelined rollout changes on the host, for an env whose save_state is complete."""
+        from . import checkpoint
+        from .wrappers import VecWrapper
+        layers, inner = [], env
+        while isinstance(inner, VecWrapper):
+            layers.append((inner, inner.snapshot_state()))
+            inner = inner.__dict__.get("env")
+        snap = {"env": copy.deepcopy(checkpoint.save_env_state(inner)), "inner": inner, "layers": layers,
+                "time": self.time.copy(),
+                "episode_score": self.episode_score.copy(), "episode_len": self.episode_len.copy(),
+                "ep_count": self.ep_count, "np_random": np.random.get_state()}
+        if self.tvf is not None:
+            snap["episode_length_buffer"] = list(self.tvf.episode_length_buffer)
+        return snap
+
+    def _chain_split_failed(self, nets, env, snap, parts):
+        """A workgroup of the two-workgroups-per-image launch gave up waiting for its partner's half of a map: the head
+        outputs of this rollout (and the actions drawn from them) cannot be trusted.  The one-workgroup launch takes
+        over for the rest of the run, and the rollout is generated again: from the saved start state where the env
+        can be put back exactly (same bytes as a run with PPO_AMD_CHAIN_SPLIT=0: the sampling counter has not
+        moved), otherwise from where the envs are now (their N steps are lost, nothing else)."""
+        from . import checkpoint
+        for n in nets:
+            n.chain_split_disable()
+        self.log.warn("the split chained launch timed out waiting for a partner workgroup: switched to one workgroup "
+                      "per image for the rest of the run and redoing this rollout"
+                      + (" from its start state" if snap is not None else " from the envs' current state"))
+        if snap is not None:
+            for wrapper, state in snap["layers"]:
+                wrapper.restore_snapshot(state)
+            checkpoint.restore_env_state(snap["inner"], snap["env"])
+            self.time = snap["time"].copy()
+            self.episode_score[:] = snap["episode_score"]
+            self.episode_len[:] = snap["episode_len"]
+            self.ep_count = snap["ep_count"]
+            np.random.set_state(snap["np_random"])
+            if self.tvf is not None:
+                self.tvf.episode_length_buffer.clear()
+                self.tvf.episode_length_buffer.extend(snap["episode_length_buffer"])
+            self._pending_episodes = []
+        elif hasattr(env, "finish_rollout"):
+            # the lost steps were real env steps: the vector wrappers' statistics take them in as usual
+            env.finish_rollout(self._rewards_host.numpy().copy(), self._dones_host.numpy().copy())
+        self._finished_lengths = [[] for _ in range(self.N)]
+        self._rollout_pipelined(parts, [])
+
+    def _rollout_pipelined(self, parts, split_nets=()):
+        """`split_nets`: the networks whose forwards may take the two-workgroups-per-image launch during this rollout
+        (the caller checks their error word afterwards)."""
+        self._split_nets_active = list(split_nets)
+        try:
+            self._rollout_pipelined_impl(parts)
+        finally:
+            for n in split_nets:
+                n.allow_chain_split = False
+
+    def _rollout_pipelined_impl(self, parts):
         N = self.N
         self.all_time[0] = self.time
         rew_np, done_np = self._rewards_host.numpy(), self._dones_host.numpy()
@@ -449,6 +521,8 @@ class Runner:
             if s_ is not main:
                 s_.wait_stream(main)
         graphs = [self._rollout_graph(i, bounds[i + 1] - bounds[i], streams[i]) if P > 1 else None for i in range(P)]
+        for n in self._split_nets_active:  # (after the graph captures: a recorded graph keeps the one-workgroup launch)
+            n.allow_chain_split = True
         norm = self.model.obs_norm
 
         # a group may be stepped (and uploaded) in several pieces: a leaf's H2D runs while the next leaf is stepped

@@ -12,11 +12,16 @@ from .running_stats import RunningMeanStd
 
 
 class VecWrapper:
+    # The group-stepping interface of the Runner's pipelined rollout is NOT inherited from the wrapped env: a wrapper
+    # that only overrides step() must see every step, so unless it defines `parts` itself (and does its per-step work in
+    # `_after_group_step` / `finish_rollout`, as the two wrappers below do) the Runner falls back to stepping it whole.
+    _NOT_FORWARDED = frozenset({"env", "parts", "finish_rollout", "step_arrays", "step_upload", "leaves", "obs_t"})
+
     def __init__(self, env):
         self.env = env
 
     def __getattr__(self, name):  # only called for attributes not found on the wrapper itself
-        if name == "env":
+        if name in VecWrapper._NOT_FORWARDED:
             raise AttributeError(name)
         return getattr(self.env, name)
 
@@ -25,6 +30,23 @@ class VecWrapper:
 
     def step(self, actions):
         return self.env.step(actions)
+
+    # A rollout can be redone from a saved state (Runner.generate_rollout after a failed split launch) when every layer
+    # can be put back exactly: a wrapper's own state is its attributes (arrays and numbers, copied), the wrapped env
+    # answers for itself.  Only wrappers that say so take part (the two below); any other falls back to "go on from here".
+    _snapshot_exact = False
+
+    @property
+    def exact_snapshot(self):
+        return self._snapshot_exact and bool(getattr(self.env, "exact_snapshot", False))
+
+    def snapshot_state(self):
+        import copy
+        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("env", "_parts")})
+
+    def restore_snapshot(self, state):
+        import copy
+        self.__dict__.update(copy.deepcopy(state))
 
     def close(self):
         return self.env.close()
@@ -69,6 +91,8 @@ def get_wrapper(env, wrapper_type):
 class VecRepeatedActionPenalty(VecWrapper):
     """Subtract `penalty` from the reward of any env that has repeated one action more than
     `max_repeated_actions` times in a row; action -1 (env skipped) neither counts nor resets."""
+
+    _snapshot_exact = True
 
     def __init__(self, env, max_repeated_actions: int, penalty: float = 1):
         super().__init__(env)
@@ -139,6 +163,7 @@ class VecNormalizeRewardWrapper(VecWrapper):
     Attribute names (`ret_rms`, `ret_var`, `current_returns`, `std`, `mean`) and the save_state keys are the
     reference's (rl/wrappers.py:795-919): checkpoints and the trainer's `reward_scale` read them."""
 
+    _snapshot_exact = True
     MODES = ("rms", "ema", "custom")
     STATE_KEYS = ("ret_rms", "ret_var", "current_returns")
     epsilon = 1e-2  # added to the variance under the square root

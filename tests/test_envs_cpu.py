@@ -186,3 +186,40 @@ def test_pool_rejects_bad_sizes_and_reports_worker_errors():
             env.restore_state({"vec_000": {"nope": 1}, "vec_001": {"nope": 1}})
     finally:
         env.close()
+
+
+def test_a_wrapper_that_only_overrides_step_is_never_bypassed_by_group_stepping():
+    """The Runner's pipelined rollout steps `env.parts` groups directly.  A VecWrapper subclass that defines neither
+    `parts` nor the group hooks must not inherit them from the env it wraps (its step() would never run): the group
+    interface is not forwarded, so the Runner sees one whole env and takes the generic path."""
+    class Inner:
+        num_envs = 4
+        parts = ["a group"]
+        exact_snapshot = True
+
+        def step_arrays(self, *a):
+            raise AssertionError("stepped behind the wrapper's back")
+
+        def finish_rollout(self, *a):
+            raise AssertionError
+
+        def something_else(self):
+            return 7
+
+    class OnlyStep(wrappers.VecWrapper):
+        def step(self, actions):
+            return "mine"
+
+    w = OnlyStep(Inner())
+    assert w.something_else() == 7 and w.num_envs == 4  # ordinary attributes still reach the wrapped env
+    for name in ("parts", "step_arrays", "finish_rollout", "step_upload", "leaves", "obs_t"):
+        assert not hasattr(w, name), name
+    assert getattr(w, "parts", [w]) == [w] and not w.exact_snapshot
+    # the two in-tree wrappers define the group interface themselves and can be put back exactly over an exact env
+    pen = wrappers.VecRepeatedActionPenalty(Inner(), 3)
+    assert "parts" in type(pen).__dict__ and pen.exact_snapshot
+    state = pen.snapshot_state()
+    pen.prev_actions[:] = 5
+    pen.duplicate_counter[:] = 9
+    pen.restore_snapshot(state)
+    assert (pen.prev_actions == 0).all() and (pen.duplicate_counter == 0).all()

@@ -440,6 +440,7 @@ def test_two_workgroups_per_image_chain_launch_is_bit_identical(gold, monkeypatc
     for split in (0, 1):
         monkeypatch.setattr(models, "CHAIN_SPLIT", split)
         net = make_net(meta)
+        net.allow_chain_split = True  # (the Runner's pipelined rollout sets this; other forwards keep one workgroup per image)
         calls = []
         orig = net._call
         net._call = lambda fn, *a: (calls.append(fn), orig(fn, *a))[1]

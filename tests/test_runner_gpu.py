@@ -127,6 +127,56 @@ def test_pipelined_rollout_equals_unsplit_rollout(runner):
         args.agents, args.n_steps = old
 
 
+def test_split_chain_timeout_is_survived_and_the_rollout_redone(runner, monkeypatch):
+    """The two-workgroups-per-image chained launch (models.CHAIN_SPLIT, default on for rollout groups <= 128 images)
+    spin-waits on a partner workgroup with a bounded spin.  Drive the timeout on purpose (control word 3: every second
+    workgroup withholds its flags): generate_rollout must not raise - it drops to the one-workgroup launch, puts the
+    (exactly restorable) synthetic env back to the rollout's start and redoes it, and the buffers of that and of the
+    following rollout are byte-identical to a run that never used the split launch."""
+    from ppo_amd import models
+    from ppo_amd.vec_env import SplitVecEnv, SyntheticVecEnv
+    old = (args.agents, args.n_steps)
+    args.agents, args.n_steps = 32, 6
+    try:
+        outs, warned = [], []
+        for split in (0, 1):
+            monkeypatch.setattr(models, "CHAIN_SPLIT", split)
+            r = rollout.Runner(runner.model, logger.Logger(quiet=True))
+            net = r.policy_net
+            net._chain_split_usable, net._plans = None, {}
+            r.log.warn = lambda msg, _w=warned: _w.append(msg)
+            r.vec_env = SplitVecEnv([SyntheticVecEnv(16, seed=5, p_done=0.05, env_offset=i * 16, threads=2) for i in range(2)])
+            r.reset()
+            r.generate_rollout()
+            if split:
+                calls = []
+                orig = net._call
+                net._call = lambda fn, *a: (calls.append(fn), orig(fn, *a))[1]
+                assert net._chain_split_usable is True and not net.chain_split_error()
+                net.chain_split_inject_fault()
+                ep_before = r.ep_count
+            r.generate_rollout()  # with split: times out, is noticed, redone on the one-workgroup launch
+            torch.cuda.synchronize()
+            snap = [x.cpu().clone() for x in (r.all_obs, r.actions, r.log_policy, r.raw_policy, r.value, r.ext_rewards,
+                                              r.terminals, r.log_pac)] + [torch.from_numpy(np.array(r.obs)),
+                                                                          torch.from_numpy(r.all_time.copy())]
+            if split:
+                assert net._chain_split_usable is False and not net.chain_split_error()
+                assert len(warned) == 1 and "redoing this rollout from its start state" in warned[0]
+                assert r.ep_count - ep_before == int(r.terminals.sum())  # episodes of the void attempt are not counted twice
+            r.generate_rollout()  # and the run goes on: no split launch any more
+            torch.cuda.synchronize()
+            if split:
+                assert "ppo_impala_stack_chain_split_forward_f32" not in calls[-40:]
+            outs.append(snap + [r.all_obs.cpu().clone(), r.actions.cpu().clone(), r.value.cpu().clone()])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert outs[0][6].any()
+    finally:
+        args.agents, args.n_steps = old
+        runner.policy_net._chain_split_usable, runner.policy_net._plans = None, {}
+
+
 def test_second_iteration_runs_and_checkpoint_round_trips(runner, tmp_path):
     r = runner
     r.generate_rollout()

@@ -100,6 +100,7 @@ def test_edges_zero_horizon_all_done_and_errors():
     (64, 5, 140, 8, "more than 128 heads: 16 result registers per lane, two register sets of records"),
     (300, 3, 20, 4, "N not a multiple of the chunk: partial last chunk, idle lanes"),
     (700, 2, 64, 2, "a column that does not fit in LDS: the prefix + gather fallback kernels"),
+    (256, 3, 48, 8, "more than 128 distinct n-steps with lane-resident records: nd * T * 8 passes 65535"),
 ])
 def test_kernel_paths_bit_exact_vs_oracle(N, A, K, C, what):
     """Every code path of csrc/tvf_returns.hip against the NumPy oracle, bit for bit."""
@@ -110,7 +111,11 @@ def test_kernel_paths_bit_exact_vs_oracle(N, A, K, C, what):
     rewards = rng.normal(size=(N, A)).astype(np.float32)
     dones = rng.random((N, A)) < 0.03
     vs = rng.normal(size=(N + 1, A, K)).astype(np.float32)
-    samples = rng.integers(1, min(N, 90) + 1, size=(K, C))
+    wide = "distinct n-steps" in what
+    samples = rng.integers(1, (N if wide else min(N, 90)) + 1, size=(K, C))
+    if wide:  # the (S, D) table's byte offset of the last n-step no longer fits in 16 bits (round 3's packing wrapped)
+        nd = len(np.unique(np.minimum(samples, hz[:, None])[hz > 0]))
+        assert nd >= 129 and C <= 8, nd
     out = R.calculate_sampled_return_multi(0.99, rewards, dones, hz, hz, vs, samples)
     ref = T.sampled_returns(0.99, rewards, dones, hz, hz, vs, samples)
     assert np.array_equal(out, ref), (what, np.abs(out - ref).max())
