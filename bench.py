@@ -852,8 +852,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{a.config}: PPO iteration, {A} envs/GPU x {N} steps, obs {tuple(obs_shape)} {obs_kind}, "
                                f"{n_actions} actions, {net_kind} ({model.model_size()} params), "
-                               f"{args.policy_opt.epochs} policy epochs, global minibatch {mb * world}, Adam, synthetic env",
-                   "envs_per_gpu": A, "n_steps": N, "global_minibatch": mb * world, "parallelism": f"dp{world}"},
+                               f"{args.policy_opt.epochs} policy epochs, global minibatch {mb * world}, Adam, synthetic env, "
+                               f"reward normalisation off (the synthetic env's rewards are N(0,1) already; the reference's "
+                               f"default 'rms' is a host-side vector wrapper, rl/config.py:508)",
+                   "reward_normalization": "off", "envs_per_gpu": A, "n_steps": N, "global_minibatch": mb * world, "parallelism": f"dp{world}"},
         "roofline": roofline,
         "phase_seconds_per_step": {k: round(v / a.steps, 4) for k, v in phase.items()},
         "model_tflops_whole_step": round(model_tflops / world, 2),

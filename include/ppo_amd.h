@@ -403,6 +403,11 @@ int ppo_normalize_f32(const float *x, int64_t n, const double *moments, float ep
 /* dst[i] += src[i], i < n: gradient accumulation over the micro-batches of a minibatch (Runner.train_batch,
  * rl/rollout.py:2331-2374, where autograd accumulates into .grad across `loss_scale = 1 / micro_batches` passes). */
 int ppo_accumulate_f32(float *dst, const float *src, int64_t n, void *stream);
+/* w[i] *= mask[i], mask in {0, 1}: DualHeadNet.mask_feature_weights (rl/models.py:425-427), the static feature mask of
+ * the TVF head (--tvf_feature_sparsity / --tvf_feature_window, rl/models.py:386-421) re-applied after every optimiser
+ * step (the reference re-applies it before every forward that evaluates the head, rl/models.py:494-497: same weights
+ * at every use). */
+int ppo_mask_mul_f32(float *w, const uint8_t *mask, int64_t n, void *stream);
 
 /*
  * Truncated-horizon (TVF) returns: the sampled weighted-n-step estimator of

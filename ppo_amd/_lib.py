@@ -53,6 +53,7 @@ SIGNATURES = {
     "ppo_moments_f64": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "ppo_normalize_f32": (_i, [_vp, _i64, _vp, _f, _vp, _vp, _vp]),
     "ppo_accumulate_f32": (_i, [_vp, _vp, _i64, _vp]),
+    "ppo_mask_mul_f32": (_i, [_vp, _vp, _i64, _vp]),
     "ppo_tvf_returns_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ppo_tvf_returns_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp, _vp]),

@@ -150,6 +150,8 @@ class TVFConfig(_Group):  # rl/config.py:209-246
         ("eta_percentile", float, 90.0, "estimated-termination trimming: percentile of episode lengths (:223)"),
         ("head_weighting", str, "off", "[off|h_weighted]"),
         ("horizon_dropout", float, 0.0, "fraction of horizons excluded per sample in the TVF loss (:224)"),
+        ("feature_window", int, -1, "limits each head to a window of this many features (:233)"),
+        ("feature_sparsity", float, 0.0, "zeros out this proportion of features for each head (:234)"),
     )
 
 

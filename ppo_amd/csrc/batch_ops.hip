@@ -114,6 +114,13 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict_
 }
 
 // dst += src, four floats per thread where the pair is 16-byte aligned (micro-batch gradient accumulation)
+// w[i] *= mask[i] (mask is 0 / 1): the reference's `tvf_head.weight.data *= tvf_features_mask` (rl/models.py:425-427)
+__global__ __launch_bounds__(256) void mask_mul_kernel(float *__restrict__ w, const uint8_t *__restrict__ mask, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = w[i] * (float)mask[i];
+}
+
 __global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n,
                                                          int vec)
 {
@@ -173,6 +180,16 @@ extern "C" int ppo_normalize_f32(const float *x, int64_t n, const double *moment
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n,
                        moments, eps, out, mean_std_out);
     return check_launch("normalize_kernel");
+}
+
+extern "C" int ppo_mask_mul_f32(float *w, const uint8_t *mask, int64_t n, void *stream)
+{
+    using namespace ppo;
+    if (n < 0) return fail(PPO_E_INVALID, "ppo_mask_mul_f32: n < 0");
+    if (n == 0) return PPO_OK;
+    if (!w || !mask) return fail(PPO_E_INVALID, "ppo_mask_mul_f32: null pointer");
+    hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, mask, n);
+    return check_launch("mask_mul_kernel");
 }
 
 extern "C" int ppo_accumulate_f32(float *dst, const float *src, int64_t n, void *stream)

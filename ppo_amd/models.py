@@ -301,8 +301,6 @@ class DualHeadNet:
             raise NotImplementedError(f"encoder '{encoder}' has no HIP path (impala | mlp)")
         if activation_fn not in ("relu", "tanh"):
             raise ValueError(f"Invalid activation function {activation_fn}")
-        if tvf_feature_sparsity > 0 or tvf_feature_window > 0:
-            raise NotImplementedError("TVF feature sparsity / windows (rl/models.py:389-421) are off by default and not built")
         _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -329,6 +327,9 @@ class DualHeadNet:
         self.col_tvf = 2 * n_actions + self.vh
         self.nh = self.col_tvf + self.K * self.vh
         self._build_parameters(head_scale)
+        self.tvf_feature_sparsity, self.tvf_feature_window = tvf_feature_sparsity, tvf_feature_window
+        self.tvf_features_mask = None
+        self._build_tvf_feature_mask()
         self._bufs: Dict[tuple, torch.Tensor] = {}
         self._rec = None   # launch recorder (see encode)
         # (n_actions, temperature, seed, offset, log_policy, actions, log_pac, raw_policy, values, n_value_heads) of
@@ -392,6 +393,45 @@ class DualHeadNet:
             self.g_b_heads = self.grad[o:o + self.nh]
         else:
             self.b_heads = self.g_b_heads = None
+
+    def _build_tvf_feature_mask(self):
+        """rl/models.py:386-421: a static mask [K, hidden] over the TVF head's weights - `tvf_feature_sparsity` zeroes a
+        random share of each head's features (the kept ones scaled by sqrt(1 / keep)), `tvf_feature_window` gives head k
+        a window of that many features sliding from the first to the last with k (scaled by sqrt(hidden / window)).
+        The initial weights are multiplied by the scaled mask; the 0 / 1 mask stays and is re-applied after every
+        optimiser step (mask_feature_weights).  The random mask comes from a CPU generator seeded 99, i.e. what the
+        reference draws on --device=cpu (on a GPU it seeds that device's generator: another stream, same law)."""
+        if not self.use_tvf or (self.tvf_feature_sparsity <= 0 and self.tvf_feature_window <= 0):
+            return
+        if self.vh != 1:  # the reference's [K, hidden] mask broadcasts against [K * vh, hidden] only then
+            raise ValueError("TVF feature masks need a single value head")
+        K, H = self.K, self.hidden_units
+        mask = torch.ones([K, H], dtype=torch.float32)
+        if self.tvf_feature_sparsity > 0:
+            keep_prob = 1 - self.tvf_feature_sparsity
+            g = torch.Generator(device="cpu")
+            g.manual_seed(99)
+            scaled = torch.bernoulli(mask * keep_prob, generator=g) * math.sqrt(1 / keep_prob)
+        if self.tvf_feature_window > 0:
+            assert self.tvf_feature_sparsity <= 0, "sparsity and feature window not supported together"
+            first_right, last_left = self.tvf_feature_window, H - self.tvf_feature_window
+            for head in range(K):
+                factor = head / (K - 1)
+                left = int(0 * (1 - factor) + last_left * factor)
+                right = int(first_right * (1 - factor) + H * factor)
+                mask[head, :left] = 0
+                mask[head, right:] = 0
+            scaled = mask * ((1 / math.sqrt(self.tvf_feature_window)) / (1 / math.sqrt(H)))
+        w = self.params["tvf_head.weight"]
+        w.mul_(scaled.to(self.device))
+        self.tvf_features_mask = torch.gt(scaled, 0).to(torch.uint8).to(self.device).contiguous()
+
+    def mask_feature_weights(self):
+        """rl/models.py:425-427; the reference calls it before every forward that evaluates the TVF head (:494-497),
+        here it follows whatever wrote the weights (optimiser step, load_state_dict): the same weights at every use."""
+        if self.tvf_features_mask is not None:
+            w = self.params["tvf_head.weight"]
+            self._call("ppo_mask_mul_f32", _p(w), _p(self.tvf_features_mask), w.numel())
 
     @property
     def early_grad_offset(self) -> int:
@@ -484,6 +524,7 @@ class DualHeadNet:
             for n, t in sd.items():
                 if n in self.params:
                     self.params[n].copy_(torch.as_tensor(t).to(self.device, torch.float32).reshape(self.params[n].shape))
+        self.mask_feature_weights()
 
     # ------------------------------------------------------------------ scratch memory
     def _buf(self, name, shape, dtype=torch.float32):
@@ -1251,10 +1292,12 @@ class DualHeadNet:
             self._call("ppo_adam_step_scatter_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step,
                        float(lr), float(beta1), float(beta2), float(eps), float(max_grad_norm), float(grad_div), _p(ws),
                        _p(grad_norm_out), _p(scatter[0]), scatter[1], _p(self._packed))
+            self.mask_feature_weights()
             return
         self._call("ppo_adam_step_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step, float(lr),
                    float(beta1), float(beta2), float(eps), float(max_grad_norm), float(grad_div), _p(ws),
                    _p(grad_norm_out))
+        self.mask_feature_weights()
 
     # ------------------------------------------------------------------ optimiser state (checkpoints)
     def parameter_order(self):

@@ -224,3 +224,51 @@ def test_tanh_kernels_match_torch():
     torch.cuda.synchronize()
     assert float((y - torch.tanh(x)).abs().max()) <= 2e-7
     assert torch.allclose(dx, dy * (1 - y * y), atol=0, rtol=0)
+
+
+MASK_GOLD = np.load(os.path.join(HERE, "golden", "tvf_mask_golden.npz"))
+MASK_META = json.load(open(os.path.join(HERE, "golden", "tvf_mask_golden.json")))
+
+
+@pytest.mark.parametrize("tag", ["sparsity", "window"])
+def test_tvf_feature_masks_match_the_reference(tag):
+    """--tvf_feature_sparsity / --tvf_feature_window (rl/models.py:386-427): a static mask over the TVF head's weights.
+    From the same seed: the masked + rescaled initial head (sha256), the 0 / 1 mask, the forward; then one optimiser
+    step with the reference's gradients - the step moves masked weights (the fixture counts them), the next forward must
+    see them zeroed again, as the reference's mask_feature_weights does."""
+    m = MASK_META[tag]
+    torch.manual_seed(7)
+    model = models.TVFModel(
+        "mlp", input_dims=tuple(m["input_dims"]), actions=m["n_actions"], device="cuda", architecture="dual",
+        hidden_units=m["hidden"], encoder_activation_fn="tanh", head_scale=m["head_scale"], head_bias=m["head_bias"],
+        tvf_fixed_head_horizons=list(MASK_GOLD["horizons"]), tvf_fixed_head_weights=None,
+        tvf_feature_sparsity=m["tvf_feature_sparsity"], tvf_feature_window=m["tvf_feature_window"])
+    import hashlib
+    for prefix, net in (("policy_net", model.policy_net), ("value_net", model.value_net)):
+        for name, t in net.state_dict().items():
+            a = np.ascontiguousarray(t.detach().cpu().numpy())
+            assert hashlib.sha256(a.tobytes()).hexdigest() == m["params"][f"{prefix}.{name}"]["sha256"], (prefix, name)
+    val = model.value_net
+    mask = MASK_GOLD[f"{tag}_mask"]
+    assert np.array_equal(val.tvf_features_mask.cpu().numpy(), mask) and 0 < mask.sum() < mask.size
+    x = cuda(MASK_GOLD["x"])
+    close(model.forward(x, output="value")["tvf_value"], MASK_GOLD[f"{tag}_fwd0_tvf_value"], 2e-6, "forward 0")
+    # one optimiser step with the reference's gradients (plain Adam, no clipping: max_grad_norm 0)
+    val.grad.zero_()
+    for name in val.params:
+        key = f"{tag}_grad_{name}"
+        if key in MASK_GOLD:
+            val.grads[name].copy_(cuda(MASK_GOLD[key]).reshape(val.grads[name].shape))
+    assert m["masked_entries_nonzero_after_step"] > 0  # the step does move masked weights in the reference
+    val.adam_step(lr=1e-2, eps=1e-5, max_grad_norm=0.0)
+    w1 = val.params["tvf_head.weight"].cpu().numpy()
+    assert (w1[mask == 0] == 0).all()
+    close(w1, MASK_GOLD[f"{tag}_w1"], 2e-6, "head after step + mask")
+    for name in val.params:
+        close(val.params[name], MASK_GOLD[f"{tag}_after_{name}"] * (mask if name == "tvf_head.weight" else 1), 2e-6, name)
+    close(model.forward(x, output="value")["tvf_value"], MASK_GOLD[f"{tag}_fwd1_tvf_value"], 5e-6, "forward 1")
+    # a loaded state_dict is masked too
+    sd = {k: v.clone() for k, v in val.state_dict().items()}
+    sd["tvf_head.weight"] = torch.ones_like(sd["tvf_head.weight"])
+    val.load_state_dict(sd)
+    assert np.array_equal(val.params["tvf_head.weight"].cpu().numpy(), mask.astype(np.float32))

@@ -34,7 +34,9 @@ def make_model(log):
         device=args.device, architecture=args.model.architecture, dtype=torch.float32,
         hidden_units=args.model.hidden_units,
         encoder_activation_fn="tanh" if args.env.type == "mujoco" else "relu",
-        tvf_fixed_head_horizons=horizons, tvf_fixed_head_weights=weights, head_scale=args.model.head_scale,
+        tvf_fixed_head_horizons=horizons, tvf_fixed_head_weights=weights,
+        tvf_feature_sparsity=args.tvf.feature_sparsity, tvf_feature_window=args.tvf.feature_window,
+        head_scale=args.model.head_scale,
         head_bias=args.model.head_bias, value_head_names=("ext",),
         observation_normalization=args.observation_normalization,
         freeze_observation_normalization=args.freeze_observation_normalization,
