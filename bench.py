@@ -88,6 +88,8 @@ def parse():
     p.add_argument("--tvf-only", action="store_true", help="only the tvf_returns section (timing / rocprofv3 passes)")
     p.add_argument("--tvf-heads", type=int, default=108, help="K = V of the tvf_returns section")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL)")
+    p.add_argument("--no-affinity", action="store_true",
+                   help="do not pin the rank (and its env threads) to the cores of its GPU's NUMA node (ppo_amd/affinity.py)")
     p.add_argument("--wall-limit", type=float, default=1500.0,
                    help="launcher: seconds after which still-running ranks are stopped and the run fails")
     p.add_argument("--dist-timeout", type=float, default=180.0, help="timeout of the process group's collectives, seconds")
@@ -662,6 +664,10 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a)
+    # first thing in a rank, before any HIP call / thread pool / pinned allocation: the cores of this GPU's NUMA node
+    from ppo_amd import affinity
+    pinned_cpus = affinity.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+                                    enabled=not a.no_affinity)
     world, rank, local = init_dist(a)
     import numpy as np
     import torch
@@ -841,6 +847,8 @@ def main():
         "unit": "env-steps/s",
         "n_gpus": world,
         "ranks_seen": parallel.world_size(),
+        "cpu_affinity": ({"cpus": len(pinned_cpus), "first": pinned_cpus[0], "last": pinned_cpus[-1]} if pinned_cpus
+                         else "unchanged (--no-affinity, one NUMA node, or no topology in sysfs)"),
         "backend": parallel.backend_name(),
         "steps": a.steps,
         "warmup": a.warmup,

@@ -318,3 +318,46 @@ def test_u8_unit_recipe_is_the_exact_quotient():
     assert int((q != want).sum()) > 0, "the bare reciprocal product is NOT exact: the correction is needed"
     got = fma(fma(q, np.float32(-255.0), x), r, q)
     assert np.array_equal(got, want)
+
+
+def test_affinity_plan_on_a_fake_two_socket_node(tmp_path):
+    """ppo_amd/affinity.py: GPU -> NUMA node from the KFD topology and the PCI device's numa_node, the node's cores
+    divided among the ranks whose GPUs share it, restricted to what the process may use; fallbacks without NUMA data."""
+    from ppo_amd import affinity
+    assert affinity.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    root = tmp_path
+    nodes = root / "sys/class/kfd/kfd/topology/nodes"
+    # KFD nodes 0, 1 are the CPU sockets (simd_count 0); GPUs 2..9: four per socket, render minors 128..135
+    for i in range(10):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        gpu = i >= 2
+        (d / "properties").write_text(f"cpu_cores_count {0 if gpu else 64}\nsimd_count {1024 if gpu else 0}\n"
+                                      + (f"drm_render_minor {126 + i}\n" if gpu else ""))
+        if gpu:
+            dev = root / f"sys/class/drm/renderD{126 + i}/device"
+            dev.mkdir(parents=True)
+            (dev / "numa_node").write_text(f"{0 if i < 6 else 1}\n")
+    for n, cpus in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        d = root / f"sys/devices/system/node/node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    r = str(root)
+    assert affinity.gpu_numa_nodes(r) == [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = range(256)
+    plans = [affinity.plan(k, 8, allowed, r, env={}) for k in range(8)]
+    assert all(len(p) == 32 for p in plans)
+    node0 = set(affinity.parse_cpulist("0-63,128-191"))
+    assert all(set(p) <= node0 for p in plans[:4]) and all(not (set(p) & node0) for p in plans[4:])
+    assert len(set().union(*map(set, plans))) == 256  # disjoint shares that cover the machine
+    # one rank alone on its socket gets the whole socket; a cpuset restriction is respected
+    assert set(affinity.plan(0, 1, allowed, r, env={})) == node0
+    assert affinity.plan(5, 8, range(64, 96), r, env={}) == list(range(72, 80))  # node 1 allowed cores 64..95, rank 5 = 2nd of 4
+    # HIP_VISIBLE_DEVICES reorders which GPU a local rank drives
+    assert not (set(affinity.plan(0, 2, allowed, r, env={"HIP_VISIBLE_DEVICES": "4,0"})) & node0)
+    # no NUMA information (numa_node -1) or no topology at all: an even split of what is allowed
+    for i in range(2, 10):
+        (root / f"sys/class/drm/renderD{126 + i}/device/numa_node").write_text("-1\n")
+    assert affinity.plan(1, 4, range(16), r, env={}) == [4, 5, 6, 7]
+    assert affinity.plan(1, 2, range(8), str(tmp_path / "nothing"), env={}) == [4, 5, 6, 7]
+    assert affinity.plan(0, 1, [3], r, env={}) is None

@@ -85,6 +85,10 @@ def main():
     args.setup()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # before any HIP call, env worker or pinned buffer: this rank's share of the cores of its GPU's NUMA node
+    # (PPO_AMD_AFFINITY=0 leaves the mask alone)
+    from ppo_amd import affinity
+    affinity.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if not torch.cuda.is_available():
         raise SystemExit("train.py: no HIP device visible; this build has no CPU path")
     torch.cuda.set_device(local)
