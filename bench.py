@@ -423,6 +423,20 @@ def _describe_call(fn, a):
     if fn == "ppo_conv3x3_block_forward_packed_f32":  # (in, pk0, b0, pk1, b1, out, n, c, h, w)
         n, c, h, w = a[6:10]
         return f"residual block fwd (2 conv) {c}ch {h}x{w}", 2 * _conv(n, c, c, h, w), None
+    if fn in ("ppo_mlp_forward_f32", "ppo_mlp_train_f32"):  # (x, net*, [grads*,] index, [x_indexed,] B, ...)
+        import ctypes
+        from ppo_amd import _lib
+        net = ctypes.cast(a[1], ctypes.POINTER(_lib.MlpNet)).contents
+        F, H, NH = net.F, net.H, net.NH
+        if fn == "ppo_mlp_forward_f32":
+            B = a[3]
+            return f"mlp forward (fc1, fc2, heads) {B}x{F}x{H} (+{NH})", 2.0 * B * (F * H + H * H + H * NH), None
+        B = a[5]
+        fwd = 2.0 * B * (F * H + H * H + H * NH)
+        return (f"mlp forward + loss + backward, 2 launches {B}x{F}x{H} (+{NH})",
+                fwd + 2.0 * B * (H * NH + H * H) + fwd, None)
+    if fn == "ppo_adam_step_presummed_f32":
+        return "clip + Adam (sums of g^2 from the gradient launch)", None, 28.0 * a[4]
     if fn == "ppo_gather_rows":
         return "gather observation rows", None, 2.0 * a[1] * a[4]
     if fn == "ppo_adam_step_f32":
@@ -654,6 +668,75 @@ def cpu_baseline(N, A, epochs, mb, obs_shape=(4, 84, 84), n_actions=6):
             "sample": f"torch-CPU restatement (oracle/model_torch.py): 1 rollout forward of {fb} obs "
                       f"({times['fwd']*1e3:.0f} ms) + 1 PPO minibatch of {tb} ({times['train']*1e3:.0f} ms) + C-oracle GAE "
                       f"scan {N}x{A} ({t_scan*1e3:.1f} ms), extrapolated to one iteration of {N*A} env steps",
+            "host_cores_available": os.cpu_count()}
+
+
+def cpu_baseline_mlp(N, A, mb, F, H, n_actions, K, epochs):
+    """configs[4] on the host through plain torch CPU ops (oracle/model_torch.mlp_forward): one rollout forward of both
+    nets over A observations, one minibatch step of each phase's network (forward, a squared-error loss over the heads
+    that phase trains, backward, clip, Adam) and the NumPy TVF-return oracle on a slice of the envs, extrapolated to one
+    iteration (`epochs` = (policy, value, distil) epochs)."""
+    import numpy as np
+    import torch
+    from oracle import model_torch as R, returns as O, returns_truncated as OT
+    from ppo_amd.models import MLPSpec, init_parameters
+    from ppo_amd import tvf as tvf_mod
+    threads = torch.get_num_threads()
+    torch.manual_seed(1)
+    spec = MLPSpec((F,), hidden_units=H)
+    nets = [init_parameters(spec, n_actions, 1, 0.1, True, K) for _ in range(2)]
+    rng = np.random.default_rng(0)
+    xf = torch.from_numpy(rng.normal(size=(A, F)).astype(np.float32))
+    xt = torch.from_numpy(rng.normal(size=(mb, F)).astype(np.float32))
+    tgt = torch.from_numpy(rng.normal(size=(mb, K)).astype(np.float32))
+    sds = [{k: v.clone().requires_grad_(True) for k, v in n.items()} for n in nets]
+    opts = [torch.optim.Adam(list(sd.values()), lr=2.5e-4, eps=1e-5) for sd in sds]
+
+    def fwd():
+        with torch.no_grad():
+            for n in nets:
+                R.mlp_forward(n, xf)
+
+    def step(i):
+        def run():
+            opts[i].zero_grad(set_to_none=True)
+            out = R.mlp_forward(sds[i], xt)
+            loss = 0.5 * torch.square(out["tvf_value"] - tgt).mean() + torch.square(out["raw_policy"]).mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for p in sds[i].values() if p.grad is not None], 20.0)
+            opts[i].step()
+        return run
+    times = {}
+    for name, fn in (("fwd", fwd), ("policy_net_step", step(0)), ("value_net_step", step(1))):
+        fn()
+        t0, reps = time.perf_counter(), 0
+        while reps < 1 or (time.perf_counter() - t0 < 3.0 and reps < 200):
+            fn()
+            reps += 1
+        times[name] = (time.perf_counter() - t0) / reps
+    # returns: GAE (C oracle) + the TVF return estimator (NumPy oracle) on 16 env columns, scaled to A
+    r = rng.normal(size=(N, A)).astype(np.float32)
+    v = rng.normal(size=(N + 1, A)).astype(np.float32)
+    d = rng.random((N, A)) < 0.01
+    t0 = time.perf_counter()
+    O.gae_and_returns(r, v[:N], v[N], d, 0.999, 0.95, 0.95)
+    t_scan = time.perf_counter() - t0
+    hz = np.asarray(tvf_mod.get_value_head_horizons(K, 30000, "geometric"))
+    As = 16
+    vs = rng.normal(size=(N + 1, As, len(hz))).astype(np.float32)
+    samples = rng.integers(1, 41, size=(len(hz), 8))
+    t0 = time.perf_counter()
+    OT.sampled_returns(0.999, r[:, :As], d[:, :As], hz, hz, vs, samples)
+    t_tvf = (time.perf_counter() - t0) * A / As
+    n_mb = N * A // mb
+    per_iter = ((N + 1) * times["fwd"] + (epochs[0] + epochs[2]) * n_mb * times["policy_net_step"]
+                + epochs[1] * n_mb * times["value_net_step"] + t_scan + t_tvf)
+    return {"value": round(N * A / per_iter, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU restatement (oracle/model_torch.mlp_forward): 1 rollout forward of both nets over {A} obs "
+                      f"({times['fwd']*1e3:.2f} ms), 1 minibatch step of {mb} per net ({times['policy_net_step']*1e3:.2f} / "
+                      f"{times['value_net_step']*1e3:.2f} ms), C-oracle GAE scan ({t_scan*1e3:.1f} ms), NumPy TVF-return oracle on "
+                      f"{As} of {A} env columns ({t_tvf*1e3:.0f} ms scaled), extrapolated to one iteration of {N*A} env steps "
+                      f"({epochs[0]} policy / {epochs[1]} value / {epochs[2]} distil epochs)",
             "host_cores_available": os.cpu_count()}
 
 
@@ -918,8 +1001,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline(N, A, args.policy_opt.epochs, mb, tuple(obs_shape), n_actions)
                                    if a.config != "humanoid_tvf" else
-                                   {"value": None, "note": "the torch-CPU restatement (oracle/model_torch.py) covers the IMPALA "
-                                                           "single-architecture path; not timed for the MLP + TVF config"})
+                                   cpu_baseline_mlp(N, A, mb, obs_shape[0], args.model.hidden_units, n_actions, runner.K,
+                                                    (args.policy_opt.epochs, args.value_opt.epochs, args.distil_opt.epochs)))
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

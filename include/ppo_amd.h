@@ -372,6 +372,12 @@ size_t ppo_adam_workspace_bytes(void);
 int ppo_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
                       double lr, double beta1, double beta2, double eps, float max_grad_norm, float grad_div,
                       void *workspace, float *grad_norm_out, void *stream);
+/* The optimiser step when the per-workgroup partial sums of g^2 already exist (written by the launch that produced the
+ * gradients: ppo_mlp_train_f32): only the Adam launch, which re-reduces `partials[0 .. n_partials)` (<= 256) in a fixed
+ * order.  Same arithmetic per parameter as ppo_adam_step_f32 (rl/rollout.py:1287-1321). */
+int ppo_adam_step_presummed_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                int64_t step, double lr, double beta1, double beta2, double eps, float max_grad_norm,
+                                float grad_div, const float *partials, int n_partials, float *grad_norm_out, void *stream);
 /* The same step that also writes every updated parameter j < n_scatter to packed[scatter[2j]] and packed[scatter[2j+1]]
  * (-1 = nowhere): the head of the flat buffer holds the convolution weights, and their pre-packed MFMA operand layouts
  * (ppo_conv3x3_pack_weights_f32: forward, and flipped / transposed for backward-data) are refreshed by the optimiser
@@ -548,6 +554,69 @@ int ppo_synth_env_step_upload(void *env, const int32_t *actions, uint8_t *obs_ou
  * [n] f32.  set_state also rewrites obs_out [n_envs, obs_bytes] with the observation those counters imply. */
 int ppo_synth_env_get_state(void *env, int64_t *steps_out, int32_t *time_out, float *score_out);
 int ppo_synth_env_set_state(void *env, const int64_t *steps, const int32_t *time, const float *score, uint8_t *obs_out);
+
+/*
+ * The MLP networks of the continuous-control / classic configs as fused launches (csrc/mlp_fused.hip):
+ *   StandardMLP  x -> fc1 -> tanh -> fc2 (rl/models.py:148-169) -> encoder activation tanh | relu (rl/models.py:456-467)
+ *   -> all heads as one [NH, H] product (rl/models.py:364-384, 470-506).
+ * ppo_mlp_forward_f32: one launch, heads [B, NH] (h_pre / hact [B, H] nullable: include_features).  Replaces the
+ *   reference's `DualHeadNet.forward` for encoder "mlp" (rl/models.py:433-508) in rollouts and evaluations.
+ * ppo_mlp_train_f32: forward + one of the four minibatch losses + backward into the gradient tensors, two launches
+ *   (rows kernel, weight-gradient kernel); replaces forward / loss / loss.backward() of Runner.train_policy_minibatch,
+ *   train_value_minibatch and train_distil_minibatch (rl/rollout.py:1610-1771, 1513-1567, 1331-1449) for these nets.
+ *   `index` (nullable, [B] int32) maps minibatch row b to its row in the per-sample loss arrays and, with x_rows > 0, in
+ *   x (x is then the whole batch of x_rows rows: the host fancy-indexing of rl/rollout.py:2349-2372 happens in the
+ *   kernel's loads; x_rows = 0: x holds the B gathered rows).
+ *   `workspace`: ppo_mlp_train_workspace_floats(B, F, H, NH) floats.  `stat_sums` (nullable): the column sums of the
+ *   per-sample statistics rows (loss->stats, n_stats columns), added to the row when stat_accumulate.
+ *   `partials` / `n_partials`: per-workgroup sums of g^2 over everything written (for ppo_adam_step_presummed_f32).
+ *   Gradients of parameters the loss does not reach are exact zeros (the reference leaves them None); dlog_std is
+ *   written by every loss kind (zeros unless gaussian).
+ */
+typedef struct ppo_mlp_net {
+    const float *w1, *b1; /* fc1 [H, F], [H] */
+    const float *w2, *b2; /* fc2 [H, H], [H] */
+    const float *wh, *bh; /* heads [NH, H], [NH] or NULL */
+    int F, H, NH;
+    int act;              /* encoder activation behind fc2: 1 tanh, 2 relu */
+} ppo_mlp_net;
+typedef struct ppo_mlp_grads {
+    float *dw1, *db1, *dw2, *db2, *dwh, *dbh; /* dbh NULL without head biases */
+    float *dlog_std;                          /* [n_log_std] or NULL */
+    int n_log_std;
+} ppo_mlp_grads;
+enum { PPO_MLP_LOSS_VALUE = 1, PPO_MLP_LOSS_DISTIL = 2, PPO_MLP_LOSS_GAUSSIAN = 3, PPO_MLP_LOSS_PPO = 4 };
+typedef struct ppo_mlp_loss {
+    int kind;         /* PPO_MLP_LOSS_* : the arguments of ppo_value_loss_f32 / ppo_distil_loss_f32 / ppo_gaussian_loss_f32 /
+                         ppo_ppo_loss_f32, same meaning */
+    float grad_scale;
+    float *stats;     /* per-sample statistics rows of that loss kernel, nullable */
+    int n_actions, n_value_heads;
+    const float *returns;
+    float vf_coef;
+    /* value */
+    int value_col, tvf_col, n_tvf, tvf_stride;
+    const float *tvf_returns, *tvf_weights;
+    float tvf_coef, tvf_keep_prob;
+    uint64_t seed, offset;
+    /* distil */
+    int pred_col, n_pred, pred_stride, vector_targets;
+    const float *targets, *weights, *old_policy, *log_std;
+    float beta;
+    /* gaussian / discrete policy */
+    const float *actions_f;
+    const int32_t *actions_i;
+    const float *old_log_pac, *old_log_policy, *advantages;
+    float eps_clip, ent_coef;
+    float *dlog_std_rows; /* gaussian: [B, n_actions] scratch */
+} ppo_mlp_loss;
+int ppo_mlp_supported(int F, int H, int NH);
+int ppo_mlp_forward_f32(const float *x, const ppo_mlp_net *net, const int32_t *index, int B, float *heads, float *h_pre,
+                        float *hact, void *stream);
+size_t ppo_mlp_train_workspace_floats(int B, int F, int H, int NH);
+int ppo_mlp_train_f32(const float *x, const ppo_mlp_net *net, const ppo_mlp_grads *grads, const int32_t *index,
+                      int64_t x_rows, int B, const ppo_mlp_loss *loss, float *workspace, float *heads, float *stat_sums,
+                      int n_stats, int stat_accumulate, float *partials, int *n_partials, void *stream);
 
 #ifdef __cplusplus
 }

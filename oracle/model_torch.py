@@ -37,6 +37,21 @@ def forward(sd, x, n_stacks=3, n_block=2):
             "advantage": F.linear(f, sd["advantage_head.weight"], sd.get("advantage_head.bias")), "h": h}
 
 
+def mlp_forward(sd, x, activation="tanh"):
+    """The MLP encoder nets (StandardMLP rl/models.py:148-169: fc1 -> tanh -> fc2; DualHeadNet's encoder activation and
+    heads rl/models.py:456-506) as plain torch ops; keys as the reference's state_dict relative to one net.  Parity:
+    pinned through tests/golden/variants_golden.npz (tests/test_oracle_model.py::test_mlp_forward_matches_reference)."""
+    h = F.linear(torch.tanh(F.linear(x, sd["encoder.fc1.weight"], sd["encoder.fc1.bias"])),
+                 sd["encoder.fc2.weight"], sd["encoder.fc2.bias"])
+    f = torch.tanh(h) if activation == "tanh" else F.relu(h)
+    out = {"raw_policy": F.linear(f, sd["policy_head.weight"], sd.get("policy_head.bias")),
+           "value": F.linear(f, sd["value_head.weight"], sd.get("value_head.bias")),
+           "advantage": F.linear(f, sd["advantage_head.weight"], sd.get("advantage_head.bias")), "h": h}
+    if "tvf_head.weight" in sd:
+        out["tvf_value"] = F.linear(f, sd["tvf_head.weight"], sd.get("tvf_head.bias"))
+    return out
+
+
 def ppo_loss(out, actions, old_log_pac, advantages, returns, eps=0.2, ent_coef=0.01, vf_coef=0.5, loss_scale=1.0):
     """mean((-gain) * loss_scale) exactly as rl/rollout.py:1640-1660,1682,1744-1753,1596-1608."""
     logps = out["log_policy"]

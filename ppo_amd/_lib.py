@@ -98,6 +98,11 @@ SIGNATURES = {
     "ppo_obs_normalize_f32": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
+    "ppo_adam_step_presummed_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _i, _vp, _vp]),
+    "ppo_mlp_supported": (_i, [_i, _i, _i]),
+    "ppo_mlp_forward_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "ppo_mlp_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "ppo_mlp_train_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ppo_adam_step_scatter_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp]),
 }
 
@@ -105,6 +110,36 @@ class PackJob(ctypes.Structure):
     """ppo_pack_job (include/ppo_amd.h)."""
     _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
                 ("transposed", ctypes.c_int)]
+
+
+class MlpNet(ctypes.Structure):
+    """ppo_mlp_net (include/ppo_amd.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w1", "b1", "w2", "b2", "wh", "bh")] + \
+               [(n, ctypes.c_int) for n in ("F", "H", "NH", "act")]
+
+
+class MlpGrads(ctypes.Structure):
+    """ppo_mlp_grads (include/ppo_amd.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("dw1", "db1", "dw2", "db2", "dwh", "dbh", "dlog_std")] + [("n_log_std", ctypes.c_int)]
+
+
+class MlpLoss(ctypes.Structure):
+    """ppo_mlp_loss (include/ppo_amd.h)."""
+    _fields_ = [("kind", ctypes.c_int), ("grad_scale", ctypes.c_float), ("stats", ctypes.c_void_p),
+                ("n_actions", ctypes.c_int), ("n_value_heads", ctypes.c_int), ("returns", ctypes.c_void_p),
+                ("vf_coef", ctypes.c_float),
+                ("value_col", ctypes.c_int), ("tvf_col", ctypes.c_int), ("n_tvf", ctypes.c_int), ("tvf_stride", ctypes.c_int),
+                ("tvf_returns", ctypes.c_void_p), ("tvf_weights", ctypes.c_void_p), ("tvf_coef", ctypes.c_float),
+                ("tvf_keep_prob", ctypes.c_float), ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
+                ("pred_col", ctypes.c_int), ("n_pred", ctypes.c_int), ("pred_stride", ctypes.c_int),
+                ("vector_targets", ctypes.c_int), ("targets", ctypes.c_void_p), ("weights", ctypes.c_void_p),
+                ("old_policy", ctypes.c_void_p), ("log_std", ctypes.c_void_p), ("beta", ctypes.c_float),
+                ("actions_f", ctypes.c_void_p), ("actions_i", ctypes.c_void_p), ("old_log_pac", ctypes.c_void_p),
+                ("old_log_policy", ctypes.c_void_p), ("advantages", ctypes.c_void_p), ("eps_clip", ctypes.c_float),
+                ("ent_coef", ctypes.c_float), ("dlog_std_rows", ctypes.c_void_p)]
+
+
+MLP_LOSS_VALUE, MLP_LOSS_DISTIL, MLP_LOSS_GAUSSIAN, MLP_LOSS_PPO = 1, 2, 3, 4
 
 
 class WgradJob(ctypes.Structure):

@@ -161,6 +161,27 @@ extern "C" int ppo_adam_step_scatter_f32(float *params, const float *grads, floa
                      grad_norm_out, scatter, n_scatter, packed, stream);
 }
 
+extern "C" int ppo_adam_step_presummed_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                           int64_t step, double lr, double beta1, double beta2, double eps,
+                                           float max_grad_norm, float grad_div, const float *partials, int n_partials,
+                                           float *grad_norm_out, void *stream)
+{
+    using namespace ppo;
+    if (n < 0 || step < 1) return fail(PPO_E_INVALID, "ppo_adam_step_presummed_f32: n < 0 or step < 1");
+    if (n == 0) return PPO_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !partials || n_partials < 1 || n_partials > kPartials)
+        return fail(PPO_E_INVALID, "ppo_adam_step_presummed_f32: null pointer or partial count outside [1, %d]", kPartials);
+    if (!(grad_div > 0.f)) return fail(PPO_E_INVALID, "ppo_adam_step_presummed_f32: grad_div must be > 0");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    int grid = (int)((n + 255) / 256);
+    grid = grid > 1024 ? 1024 : grid;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n, partials,
+                       n_partials, (float)lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)bc1,
+                       (float)sqrt(bc2), max_grad_norm, grad_div, grad_norm_out, nullptr, (int64_t)0, nullptr);
+    return check_launch("adam_kernel");
+}
+
 static int adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, double lr,
                      double beta1, double beta2, double eps, float max_grad_norm, float grad_div, void *workspace,
                      float *grad_norm_out, const int32_t *scatter, int64_t n_scatter, float *packed, void *stream)

@@ -87,6 +87,11 @@ FUSE_STACK16_MIN_BATCH = int(os.environ.get("PPO_AMD_FUSE_STACK16_MIN_BATCH", "1
 # Below that batch an inference forward runs each 16-channel residual block as one launch (csrc/conv3x3_block.hip: band by
 # band, the intermediate map in LDS) instead of two convolution launches: a 128-image group is launch-cost-bound there.
 FUSE_BLOCK = int(os.environ.get("PPO_AMD_FUSE_BLOCK", "1"))
+# MLP nets (encoder "mlp": the continuous-control and classic configs) run as fused launches (csrc/mlp_fused.hip): one
+# per inference forward, three per training minibatch (rows kernel: forward + loss + backward-data; weight gradients +
+# statistics; Adam) instead of ~14 launches of 8 - 20 us each.  0 = the op-by-op path (same arithmetic per element up to
+# float32 summation order; tests/test_variants_gpu.py runs both against the reference's fixtures).
+FUSE_MLP = int(os.environ.get("PPO_AMD_FUSE_MLP", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -201,6 +206,31 @@ def init_parameters(spec, n_actions: int, vh: int, head_scale: float, head_bias:
 
 def init_impala_parameters(spec: ImpalaSpec, n_actions: int, vh: int, head_scale: float, head_bias: bool):
     return init_parameters(spec, n_actions, vh, head_scale, head_bias)
+
+
+def tvf_feature_mask(K: int, H: int, sparsity: float, window: int) -> torch.Tensor:
+    """The scaled mask [K, H] of rl/models.py:386-421 (CPU tensor): `sparsity` keeps each (head, feature) with probability
+    1 - sparsity and scales the kept ones by sqrt(1 / keep) - drawn from a CPU generator seeded 99, i.e. what the reference
+    draws on --device=cpu (torch's CPU generators give the same stream only on hosts that take the same vector code path);
+    `window` gives head k the features [left_k, right_k), the window sliding from the first to the last feature with k,
+    scaled by sqrt(H / window)."""
+    mask = torch.ones([K, H], dtype=torch.float32)
+    if sparsity > 0:
+        keep_prob = 1 - sparsity
+        g = torch.Generator(device="cpu")
+        g.manual_seed(99)
+        scaled = torch.bernoulli(mask * keep_prob, generator=g) * math.sqrt(1 / keep_prob)
+    if window > 0:
+        assert sparsity <= 0, "sparsity and feature window not supported together"
+        first_right, last_left = window, H - window
+        for head in range(K):
+            factor = head / (K - 1)
+            left = int(0 * (1 - factor) + last_left * factor)
+            right = int(first_right * (1 - factor) + H * factor)
+            mask[head, :left] = 0
+            mask[head, right:] = 0
+        scaled = mask * ((1 / math.sqrt(window)) / (1 / math.sqrt(H)))
+    return scaled
 
 
 def plan_input_keys(kind):
@@ -344,6 +374,7 @@ class DualHeadNet:
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self.use_plans = True  # False: every inference launch goes through _call (bench.py's per-kernel table brackets it)
         self._build_packed_weights()
+        self._build_mlp_fused()
         self._adam_step = 0
         self.exp_avg = None
         self.exp_avg_sq = None
@@ -394,6 +425,54 @@ class DualHeadNet:
         else:
             self.b_heads = self.g_b_heads = None
 
+    def _build_mlp_fused(self):
+        """The pointer tables of the fused MLP launches (the flat buffers never move)."""
+        self.mlp_fused, self._presummed = False, 0
+        sp = self.spec
+        if not FUSE_MLP or self.encoder_kind != "mlp" or \
+                not self.lib.ppo_mlp_supported(sp.in_features, sp.hidden_units, self.nh):
+            return
+        P, G = self.params, self.grads
+        self._mlp_net = _lib.MlpNet(
+            w1=_p(P["encoder.fc1.weight"]), b1=_p(P["encoder.fc1.bias"]), w2=_p(P["encoder.fc2.weight"]),
+            b2=_p(P["encoder.fc2.bias"]), wh=_p(self.w_heads), bh=_p(self.b_heads), F=sp.in_features, H=sp.hidden_units,
+            NH=self.nh, act=1 if self.encoder_activation_fn == "tanh" else 2)
+        self._mlp_grads = _lib.MlpGrads(
+            dw1=_p(G["encoder.fc1.weight"]), db1=_p(G["encoder.fc1.bias"]), dw2=_p(G["encoder.fc2.weight"]),
+            db2=_p(G["encoder.fc2.bias"]), dwh=_p(self.g_w_heads), dbh=_p(self.g_b_heads), dlog_std=_p(G["log_std"]),
+            n_log_std=self.n_actions)
+        self._mlp_loss = _lib.MlpLoss()
+        self._mlp_npart = ctypes.c_int(0)
+        self.mlp_fused = True
+
+    def _mlp_train(self, kind, prev_state, index, stats, n_stats, stat_sums, stat_accumulate, **fields):
+        """Forward + loss `kind` + backward of one minibatch through the fused launches; the gradients land in
+        self.grad, the per-workgroup sums of g^2 in the optimiser's workspace (adam_step picks them up)."""
+        B = int(index.shape[0]) if index is not None else int(prev_state.shape[0])
+        x = prev_state
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("the mlp encoder takes contiguous float32 observations")
+        x_indexed = int(x.shape[0]) if (index is not None and x.shape[0] != B) else 0  # rows of the whole batch
+        if self.obs_norm is not None:
+            if x_indexed:
+                raise ValueError("observation normalisation needs the gathered minibatch")
+            xn = self._buf("txn", tuple(x.shape))
+            self._call("ppo_obs_normalize_f32", _p(x), 0, _p(self.obs_norm.mu), _p(self.obs_norm.std),
+                       self.obs_norm.norm_eps, _p(xn), x.shape[0], self.obs_norm.F)
+            x = xn
+        L = self._mlp_loss
+        L.kind, L.stats = kind, _p(stats)
+        for k, v in fields.items():
+            setattr(L, k, v)
+        H = self.hidden_units
+        ws = self._buf("mlp_ws", (int(self.lib.ppo_mlp_train_workspace_floats(B, self.spec.in_features, H, self.nh)),))
+        partials = self._ws("adam_ws", self.lib.ppo_adam_workspace_bytes())
+        self._call("ppo_mlp_train_f32", _p(x), ctypes.addressof(self._mlp_net), ctypes.addressof(self._mlp_grads), _p(index),
+                   x_indexed, B, ctypes.addressof(L), _p(ws), None, _p(stat_sums), n_stats, 1 if stat_accumulate else 0,
+                   _p(partials), ctypes.addressof(self._mlp_npart))
+        self._presummed = self._mlp_npart.value
+        return stats
+
     def _build_tvf_feature_mask(self):
         """rl/models.py:386-421: a static mask [K, hidden] over the TVF head's weights - `tvf_feature_sparsity` zeroes a
         random share of each head's features (the kept ones scaled by sqrt(1 / keep)), `tvf_feature_window` gives head k
@@ -405,23 +484,7 @@ class DualHeadNet:
             return
         if self.vh != 1:  # the reference's [K, hidden] mask broadcasts against [K * vh, hidden] only then
             raise ValueError("TVF feature masks need a single value head")
-        K, H = self.K, self.hidden_units
-        mask = torch.ones([K, H], dtype=torch.float32)
-        if self.tvf_feature_sparsity > 0:
-            keep_prob = 1 - self.tvf_feature_sparsity
-            g = torch.Generator(device="cpu")
-            g.manual_seed(99)
-            scaled = torch.bernoulli(mask * keep_prob, generator=g) * math.sqrt(1 / keep_prob)
-        if self.tvf_feature_window > 0:
-            assert self.tvf_feature_sparsity <= 0, "sparsity and feature window not supported together"
-            first_right, last_left = self.tvf_feature_window, H - self.tvf_feature_window
-            for head in range(K):
-                factor = head / (K - 1)
-                left = int(0 * (1 - factor) + last_left * factor)
-                right = int(first_right * (1 - factor) + H * factor)
-                mask[head, :left] = 0
-                mask[head, right:] = 0
-            scaled = mask * ((1 / math.sqrt(self.tvf_feature_window)) / (1 / math.sqrt(H)))
+        scaled = tvf_feature_mask(self.K, self.hidden_units, self.tvf_feature_sparsity, self.tvf_feature_window)
         w = self.params["tvf_head.weight"]
         w.mul_(scaled.to(self.device))
         self.tvf_features_mask = torch.gt(scaled, 0).to(torch.uint8).to(self.device).contiguous()
@@ -633,7 +696,7 @@ class DualHeadNet:
                            _p(self.obs_norm.std), self.obs_norm.norm_eps, _p(x_in), x.shape[0], self.obs_norm.F)
             acts = (self._encode_mlp(x_in, train, tag) if self.encoder_kind == "mlp"
                     else self._encode_impala(x_in, train, tag))
-            if self.encoder_activation_fn == "tanh":
+            if self.encoder_activation_fn == "tanh" and "heads" not in acts:
                 h = acts["h"]
                 hact = self._buf(tag + "hact", tuple(h.shape))
                 self._call("ppo_tanh_forward_f32", _p(h), _p(hact), h.numel())
@@ -650,6 +713,13 @@ class DualHeadNet:
         if x.dtype != torch.float32:
             raise ValueError("the mlp encoder takes float32 observations")
         sp, B = self.spec, x.shape[0]
+        if self.mlp_fused and not train:
+            # the whole net in one launch: heads, and the encoder output before / after its activation
+            o = self._buf(f"{tag}heads", (B, self.nh))
+            h = self._buf(f"{tag}h", (B, sp.hidden_units))
+            hact = self._buf(f"{tag}hact", (B, sp.hidden_units))
+            self._call("ppo_mlp_forward_f32", _p(x), ctypes.addressof(self._mlp_net), None, B, _p(o), _p(h), _p(hact))
+            return {"x": x, "h": h, "hact": hact, "heads": o}
         z1 = self._buf(f"{tag}z1", (B, sp.hidden_units))
         self._linear(x, sp.in_features, "encoder.fc1", z1, tag=tag)
         a1 = self._buf(f"{tag}a1", (B, sp.hidden_units))
@@ -1203,13 +1273,23 @@ class DualHeadNet:
         return acts, o, B, self._buf("dheads", (B, self.nh))
 
     def ppo_minibatch(self, prev_state, actions, old_log_pac, old_log_policy, advantages, returns,
-                      eps_clip=0.2, ent_coef=0.01, vf_coef=0.5, loss_scale=1.0, index=None):
+                      eps_clip=0.2, ent_coef=0.01, vf_coef=0.5, loss_scale=1.0, index=None, stat_sums=None,
+                      stat_accumulate=False):
         """Forward, fused PPO loss, backward: gradients of mean(-gain)*loss_scale land in self.grad
         (Runner.train_policy_minibatch, rl/rollout.py:1610-1771; discrete actions).  vf_coef = 0 (and
         returns None) leaves the value head out, as the dual architecture's policy phase does (:1744).
         prev_state is the (already gathered) minibatch of observations; the per-sample arrays are
         either minibatch-sized or, with ``index`` ([B] int32), whole-batch arrays read at index[b].
-        Returns the per-sample statistics tensor [B, 8] (device)."""
+        Returns the per-sample statistics tensor [B, 8] (device).  MLP nets on the fused path (mlp_fused) also take
+        the whole batch of observations as prev_state (rows read through ``index``) and ``stat_sums``, a device row
+        that receives the column sums of the statistics."""
+        if self.mlp_fused:
+            B = int(index.shape[0]) if index is not None else int(prev_state.shape[0])
+            return self._mlp_train(
+                _lib.MLP_LOSS_PPO, prev_state, index, self._buf("loss_stats", (B, 8)), 8, stat_sums, stat_accumulate,
+                grad_scale=float(loss_scale) / B, n_actions=self.n_actions, n_value_heads=self.vh if returns is not None else 0,
+                returns=_p(returns), vf_coef=float(vf_coef), actions_i=_p(actions), old_log_pac=_p(old_log_pac),
+                old_log_policy=_p(old_log_policy), advantages=_p(advantages), eps_clip=float(eps_clip), ent_coef=float(ent_coef))
         acts, o, B, dheads = self._train_forward(prev_state)
         stats = self._buf("loss_stats", (B, 8))
         vh = self.vh if returns is not None else 0
@@ -1220,8 +1300,16 @@ class DualHeadNet:
         return stats
 
     def gaussian_minibatch(self, prev_state, actions, old_log_pac, advantages, returns, eps_clip=0.2, vf_coef=0.5,
-                           loss_scale=1.0, index=None):
+                           loss_scale=1.0, index=None, stat_sums=None, stat_accumulate=False):
         """As ppo_minibatch for gaussian policies (rl/rollout.py:1693-1704); also fills log_std's gradient."""
+        if self.mlp_fused:
+            B = int(index.shape[0]) if index is not None else int(prev_state.shape[0])
+            return self._mlp_train(
+                _lib.MLP_LOSS_GAUSSIAN, prev_state, index, self._buf("loss_stats", (B, 8)), 8, stat_sums, stat_accumulate,
+                grad_scale=float(loss_scale) / B, n_actions=self.n_actions, n_value_heads=self.vh if returns is not None else 0,
+                returns=_p(returns), vf_coef=float(vf_coef), actions_f=_p(actions), old_log_pac=_p(old_log_pac),
+                advantages=_p(advantages), log_std=_p(self.params["log_std"]), eps_clip=float(eps_clip),
+                dlog_std_rows=_p(self._buf("dlog_std_rows", (B, self.n_actions))))
         acts, o, B, dheads = self._train_forward(prev_state)
         stats = self._buf("loss_stats", (B, 8))
         rows = self._buf("dlog_std_rows", (B, self.n_actions))
@@ -1235,9 +1323,19 @@ class DualHeadNet:
         return stats
 
     def value_minibatch(self, prev_state, returns=None, tvf_returns=None, tvf_weights=None, vf_coef=0.5,
-                        tvf_coef=1.0, loss_scale=1.0, index=None, tvf_keep_prob=1.0, dropout_seed=0, dropout_offset=0):
+                        tvf_coef=1.0, loss_scale=1.0, index=None, tvf_keep_prob=1.0, dropout_seed=0, dropout_offset=0,
+                        stat_sums=None, stat_accumulate=False):
         """Value phase (Runner.train_value_minibatch, rl/rollout.py:1513-1567; TVF loss rl/tvf.py:32-77, with
         horizon dropout when tvf_keep_prob < 1: :64-69)."""
+        if self.mlp_fused:
+            B = int(index.shape[0]) if index is not None else int(prev_state.shape[0])
+            return self._mlp_train(
+                _lib.MLP_LOSS_VALUE, prev_state, index, self._buf("value_stats", (B, 4)), 4, stat_sums, stat_accumulate,
+                grad_scale=float(loss_scale) / B, value_col=self.col_value, n_value_heads=self.vh if returns is not None else 0,
+                returns=_p(returns), vf_coef=float(vf_coef), tvf_col=self.col_tvf if self.K else 0,
+                n_tvf=self.K if tvf_returns is not None else 0, tvf_stride=max(self.vh, 1), tvf_returns=_p(tvf_returns),
+                tvf_weights=_p(tvf_weights), tvf_coef=float(tvf_coef), tvf_keep_prob=float(tvf_keep_prob),
+                seed=int(dropout_seed) & (2**64 - 1), offset=int(dropout_offset) & (2**64 - 1))
         acts, o, B, dheads = self._train_forward(prev_state)
         stats = self._buf("value_stats", (B, 4))
         self._call("ppo_value_loss_f32", _p(o), B, self.nh, self.col_value, self.vh if returns is not None else 0,
@@ -1249,17 +1347,33 @@ class DualHeadNet:
         return stats
 
     def distil_minibatch(self, prev_state, targets, old_policy, beta=1.0, use_tvf=False, weights=None, gaussian=False,
-                         loss_scale=1.0, index=None):
+                         loss_scale=1.0, index=None, stat_sums=None, stat_accumulate=False):
         """Distillation phase (Runner.train_distil_minibatch, rl/rollout.py:1331-1449): targets [*] against the
         ext value head, or [*, K] against the TVF heads' ext column (use_tvf)."""
+        col, n_pred, stride = (self.col_tvf, self.K, self.vh) if use_tvf else (self.col_value, 1, 1)
+        if self.mlp_fused:
+            B = int(index.shape[0]) if index is not None else int(prev_state.shape[0])
+            return self._mlp_train(
+                _lib.MLP_LOSS_DISTIL, prev_state, index, self._buf("distil_stats", (B, 4)), 4, stat_sums, stat_accumulate,
+                grad_scale=float(loss_scale) / B, n_actions=self.n_actions, pred_col=col, n_pred=n_pred, pred_stride=stride,
+                vector_targets=1 if use_tvf else 0, targets=_p(targets), weights=_p(weights), old_policy=_p(old_policy),
+                log_std=_p(self.params["log_std"]) if gaussian else None, beta=float(beta))
         acts, o, B, dheads = self._train_forward(prev_state)
         stats = self._buf("distil_stats", (B, 4))
-        col, n_pred, stride = (self.col_tvf, self.K, self.vh) if use_tvf else (self.col_value, 1, 1)
         self._call("ppo_distil_loss_f32", _p(o), B, self.nh, self.n_actions, col, n_pred, stride, 1 if use_tvf else 0,
                    _p(targets), _p(weights), _p(old_policy), _p(self.params["log_std"]) if gaussian else None,
                    float(beta), float(loss_scale) / B, _p(dheads), _p(stats), _p(index))
         self.backward(acts, dheads)
         return stats
+
+    def last_dheads(self, B):
+        """d loss / d heads [B, nh] of the last training minibatch (a view of scratch memory, for tests and diagnostics):
+        the fused MLP path keeps it at the end of its workspace, the op-by-op path in its own buffer."""
+        if self.mlp_fused:
+            ws = self._buf("mlp_ws", (int(self.lib.ppo_mlp_train_workspace_floats(B, self.spec.in_features, self.hidden_units,
+                                                                                   self.nh)),))
+            return ws[4 * B * self.hidden_units:4 * B * self.hidden_units + B * self.nh].view(B, self.nh)
+        return self._buf("dheads", (B, self.nh))
 
     def zero_untouched_grads(self):
         """log_std only receives gradient from the gaussian policy loss; every other parameter is overwritten
@@ -1287,6 +1401,14 @@ class DualHeadNet:
                 self.exp_avg_sq = torch.zeros_like(self.flat)
             self._adam_step += 1
             m, v, step = self.exp_avg, self.exp_avg_sq, self._adam_step
+        n_part, self._presummed = self._presummed, 0
+        if n_part and scatter is None and grad_div == 1.0:
+            # the launch that wrote the gradients left the per-workgroup sums of g^2 in the workspace (fused MLP path)
+            self._call("ppo_adam_step_presummed_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step,
+                       float(lr), float(beta1), float(beta2), float(eps), float(max_grad_norm), float(grad_div), _p(ws),
+                       n_part, _p(grad_norm_out))
+            self.mask_feature_weights()
+            return
         if scatter is not None:
             # the step also refreshes the convolution kernels' packed operands: no re-pack launch before the next forward
             self._call("ppo_adam_step_scatter_f32", _p(self.flat), _p(self.grad), _p(m), _p(v), self.flat.numel(), step,

@@ -797,6 +797,7 @@ class Runner:
         def finish(self):
             if self.count > 1:
                 self.net.grad.copy_(self.acc)
+                self.net._presummed = 0  # the last pass's sums of g^2 are not the accumulated gradient's
             self.restore_hook()
 
         def restore_hook(self):
@@ -818,7 +819,10 @@ class Runner:
         micro, n_micro = self._micro_batches(mb)
         obs_rows = self.all_obs[:self.N].view(B, -1)
         row_bytes = obs_rows.shape[1] * obs_rows.element_size()
-        mb_obs = net._buf("mb_obs", (micro, *self.state_shape), self.all_obs.dtype)
+        # MLP nets on the fused path read their rows of the whole batch through the permutation and column-sum the
+        # statistics in their weight-gradient launch: no gather launch, no column-sum launch
+        fused = bool(getattr(net, "mlp_fused", False)) and net.obs_norm is None and self.all_obs.dtype == torch.float32
+        mb_obs = None if fused else net._buf("mb_obs", (micro, *self.state_shape), self.all_obs.dtype)
         stat_rows = net._buf(f"stat_rows_{label}", (epochs * n_mb, n_stats))
         norm_rows = net._buf(f"norm_rows_{label}", (epochs * n_mb,))
         k = 0
@@ -831,6 +835,10 @@ class Runner:
                 try:
                     for u in range(n_micro):
                         idx = order_dev[j * mb + u * micro:j * mb + (u + 1) * micro]
+                        if fused:
+                            step_fn(obs_rows, idx, 1.0 / n_micro, stat_sums=stat_rows[k], stat_accumulate=bool(u))
+                            acc.after_backward()
+                            continue
                         self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), micro, _p(mb_obs))
                         stats = step_fn(mb_obs, idx, 1.0 / n_micro)
                         acc.after_backward()
@@ -853,17 +861,17 @@ class Runner:
         returns = None if self.dual else self.returns
         net.zero_untouched_grads()
         if self.action_dist == "discrete":
-            def step(mb_obs, idx, loss_scale):
+            def step(mb_obs, idx, loss_scale, **kw):
                 return net.ppo_minibatch(mb_obs, self.actions, self.log_pac, self.log_policy, self.norm_advantage,
                                          returns, eps_clip=self.ppo_epsilon, ent_coef=self.current_entropy_bonus,
-                                         vf_coef=args.ppo_vf_coef, loss_scale=loss_scale, index=idx)
+                                         vf_coef=args.ppo_vf_coef, loss_scale=loss_scale, index=idx, **kw)
         else:
             actions, log_pac = self.actions.view(B, self.n_actions), self.log_pac.view(B, self.n_actions)
 
-            def step(mb_obs, idx, loss_scale):
+            def step(mb_obs, idx, loss_scale, **kw):
                 return net.gaussian_minibatch(mb_obs, actions, log_pac, self.norm_advantage, returns,
                                               eps_clip=self.ppo_epsilon, vf_coef=args.ppo_vf_coef, loss_scale=loss_scale,
-                                              index=idx)
+                                              index=idx, **kw)
         self._run_epochs("policy", self.policy_optimizer, args.policy_opt.epochs, args.policy_opt.mini_batch_size,
                          step, 8)
 
@@ -883,11 +891,11 @@ class Runner:
         keep = 1.0 - args.tvf.horizon_dropout if self.tvf is not None else 1.0
         seed = self._device_seed * 1000003 + 7919 * (self.rank + 1)
 
-        def step(mb_obs, idx, loss_scale):
-            off = self.tvf.next_dropout_offset(mb_obs.shape[0] * self.K) if keep < 1.0 else 0
+        def step(mb_obs, idx, loss_scale, **kw):
+            off = self.tvf.next_dropout_offset(idx.shape[0] * self.K) if keep < 1.0 else 0
             return net.value_minibatch(mb_obs, returns=returns, tvf_returns=tvf_returns, tvf_weights=weights,
                                        vf_coef=args.ppo_vf_coef, tvf_coef=args.tvf.coef, loss_scale=loss_scale, index=idx,
-                                       tvf_keep_prob=keep, dropout_seed=seed, dropout_offset=off)
+                                       tvf_keep_prob=keep, dropout_seed=seed, dropout_offset=off, **kw)
         self._run_epochs("value", self.value_optimizer, args.value_opt.epochs, args.value_opt.mini_batch_size, step, 4)
 
     def wants_distil_update(self, location=None):
@@ -939,10 +947,10 @@ class Runner:
         weights = self._tvf_weights_dev if batch["use_tvf"] else None
         net.zero_untouched_grads()
 
-        def step(mb_obs, idx, loss_scale):
+        def step(mb_obs, idx, loss_scale, **kw):
             return net.distil_minibatch(mb_obs, batch["distil_targets"], batch["old_policy"], beta=args.distil.beta,
                                         use_tvf=batch["use_tvf"], weights=weights, gaussian=gaussian,
-                                        loss_scale=loss_scale, index=idx)
+                                        loss_scale=loss_scale, index=idx, **kw)
         opt = self.policy_optimizer if args.distil.use_policy_opt else self.distil_optimizer
         self._run_epochs("distil", Optimizer(net, args.distil_opt, opt.state), args.distil_opt.epochs,
                          args.distil_opt.mini_batch_size, step, 4)

@@ -54,6 +54,7 @@ def main():
             for n, p in n_.named_parameters():
                 a = p.detach().numpy()
                 m["params"][f"{prefix}.{n}"] = {"shape": list(a.shape), "sha256": hashlib.sha256(a.tobytes()).hexdigest()}
+                out[f"{tag}_init_{prefix}.{n}"] = a.copy()
         out[f"{tag}_mask"] = net.tvf_features_mask.numpy().copy()
         out[f"{tag}_w0"] = net.tvf_head.weight.detach().numpy().copy()
         with torch.no_grad():

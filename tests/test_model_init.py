@@ -63,3 +63,24 @@ def test_mlp_dual_tvf_initial_parameters_match_reference_bitwise(golden_dir):
                 a = np.ascontiguousarray(init[name].numpy())
                 assert list(a.shape) == info["shape"], name
                 assert hashlib.sha256(a.tobytes()).hexdigest() == info["sha256"], (tag, prefix, name)
+
+
+@pytest.mark.parametrize("tag", ["sparsity", "window"])
+def test_tvf_feature_masks_and_masked_initial_head_match_reference_bitwise(golden_dir, tag):
+    """--tvf_feature_sparsity / --tvf_feature_window (rl/models.py:386-421; tests/golden/make_tvf_mask_golden.py): the
+    0 / 1 mask and the masked, rescaled initial TVF head from the same seeds as the reference, bit for bit (on this
+    host: the fixture's own)."""
+    from ppo_amd.models import MLPSpec, init_parameters, tvf_feature_mask
+    meta = json.load(open(os.path.join(golden_dir, "tvf_mask_golden.json")))[tag]
+    gold = np.load(os.path.join(golden_dir, "tvf_mask_golden.npz"))
+    K, H = len(gold["horizons"]), meta["hidden"]
+    scaled = tvf_feature_mask(K, H, meta["tvf_feature_sparsity"], meta["tvf_feature_window"])
+    assert np.array_equal(torch.gt(scaled, 0).to(torch.uint8).numpy(), gold[f"{tag}_mask"])
+    torch.manual_seed(7)
+    spec = MLPSpec(tuple(meta["input_dims"]), hidden_units=H)
+    for prefix in ("policy_net", "value_net"):
+        init = init_parameters(spec, meta["n_actions"], 1, meta["head_scale"], meta["head_bias"], K)
+        init["tvf_head.weight"] = init["tvf_head.weight"] * scaled  # DualHeadNet._build_tvf_feature_mask
+        for name, t in init.items():
+            assert np.array_equal(t.numpy(), gold[f"{tag}_init_{prefix}.{name}"]), (prefix, name)
+    assert np.array_equal(gold[f"{tag}_init_value_net.tvf_head.weight"], gold[f"{tag}_w0"])

@@ -49,3 +49,27 @@ def test_loss_and_gradients_match_reference(golden_dir):
         got = got[::stride] if name == "encoder.dense.weight" else got
         ref = g["grad0_" + name]
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), name
+
+
+def test_mlp_forward_matches_reference(golden_dir):
+    """oracle/model_torch.mlp_forward (bench.py's cpu_baseline for the MLP + TVF config) against the reference's own
+    forward outputs for the MLP variants (tests/golden/variants_golden.npz): both nets of the dual architecture."""
+    from ppo_amd.models import MLPSpec, init_parameters
+    g = np.load(os.path.join(golden_dir, "variants_golden.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "variants_golden.json")))
+    for tag in ("mlp_gauss_tvf", "mlp_disc"):
+        m = meta[tag]
+        K = len(g[f"{tag}_tvf_horizons"]) if f"{tag}_tvf_horizons" in g else 0
+        torch.manual_seed(7)
+        spec = MLPSpec(tuple(m["input_dims"]), hidden_units=m["hidden"])
+        pol = init_parameters(spec, m["n_actions"], 1, m["head_scale"], m["head_bias"], K)
+        val = init_parameters(spec, m["n_actions"], 1, m["head_scale"], m["head_bias"], K)
+        x = torch.from_numpy(g[f"{tag}_x"])
+        with torch.no_grad():
+            op, ov = R.mlp_forward(pol, x, m["activation"]), R.mlp_forward(val, x, m["activation"])
+        for key, got in (("policy_raw_policy", op["raw_policy"]), ("value_value", ov["value"])):
+            ref = g[f"{tag}_fwd_full_{key}"]
+            assert np.abs(got.numpy().reshape(ref.shape) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0), (tag, key)
+        if K:
+            ref = g[f"{tag}_fwd_value_tvf_value"]
+            assert np.abs(ov["tvf_value"].numpy().reshape(ref.shape) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0)

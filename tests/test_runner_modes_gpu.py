@@ -285,11 +285,11 @@ def test_tvf_trimming_and_horizon_dropout_through_the_runner():
     tvf_ret = r.tvf.tvf_returns[:8, :, :, 0].reshape(B, K).contiguous()
     w = torch.ones(K, device="cuda")
     net.value_minibatch(obs, tvf_returns=tvf_ret, tvf_weights=w, tvf_coef=1.0)
-    full = net._buf("dheads", (B, net.nh))[:, net.col_tvf:].clone()
+    full = net.last_dheads(B)[:, net.col_tvf:].clone()
     net.value_minibatch(obs, tvf_returns=tvf_ret, tvf_weights=w, tvf_coef=1.0, tvf_keep_prob=0.5, dropout_seed=5, dropout_offset=0)
-    d1 = net._buf("dheads", (B, net.nh))[:, net.col_tvf:].clone()
+    d1 = net.last_dheads(B)[:, net.col_tvf:].clone()
     net.value_minibatch(obs, tvf_returns=tvf_ret, tvf_weights=w, tvf_coef=1.0, tvf_keep_prob=0.5, dropout_seed=5, dropout_offset=B * K)
-    d2 = net._buf("dheads", (B, net.nh))[:, net.col_tvf:].clone()
+    d2 = net.last_dheads(B)[:, net.col_tvf:].clone()
     live = full != 0
     kept = (d1 != 0) & live
     assert 0.35 < float(kept.sum()) / float(live.sum()) < 0.65
