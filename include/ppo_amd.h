@@ -618,6 +618,28 @@ int ppo_mlp_train_f32(const float *x, const ppo_mlp_net *net, const ppo_mlp_grad
                       int64_t x_rows, int B, const ppo_mlp_loss *loss, float *workspace, float *heads, float *stat_sums,
                       int n_stats, int stat_accumulate, float *partials, int *n_partials, void *stream);
 
+/*
+ * OPT-IN reduced precision (csrc/stack_bf16x3.hip): the residual blocks of a 32-channel stack (the launch
+ * ppo_impala_stack_tail_forward_f32 makes in exact float32) with every convolution as three bf16 MFMAs on (hi, lo)
+ * splits of weights and activations, float32 accumulation - ~16-bit products.  Counterpart in the reference: its
+ * `--precision` flag (train.py:166-178), whose default `medium` lets cuDNN run the convolutions in TF32 (10-bit
+ * products); the default here, and the benchmark, stay exact float32.
+ *   ppo_impala_stack_tail_pack_bf16x3   weights[4] (raw [32, 32, 3, 3] float32) -> packed
+ *                                       (ppo_impala_stack_tail_bf16x3_packed_bytes() bytes).  Forward: block0.conv0,
+ *                                       block0.conv1, block1.conv0, block1.conv1, transposed = 0.  Backward-data:
+ *                                       block1.conv1, block1.conv0, block0.conv1, block0.conv0, transposed = 1.
+ *   ppo_impala_stack_tail_forward_bf16x3   as ppo_impala_stack_tail_forward_f32: a0 / q0 / a1 nullable (inference)
+ *   ppo_impala_stack_tail_backward_bf16x3  as ppo_impala_stack_tail_backward_f32 (masks: a1, q0, a0, p)
+ * 32 channels at 21x21 or 11x11 (ppo_impala_stack_tail_bf16x3_supported).
+ */
+size_t ppo_impala_stack_tail_bf16x3_packed_bytes(void);
+int ppo_impala_stack_tail_bf16x3_supported(int channels, int h, int w);
+int ppo_impala_stack_tail_pack_bf16x3(const float *const *weights, void *packed, int channels, int transposed, void *stream);
+int ppo_impala_stack_tail_forward_bf16x3(const float *in, const void *packed, const float *const *biases, float *a0, float *q0,
+                                         float *a1, float *q1, int n_images, int channels, int h, int w, void *stream);
+int ppo_impala_stack_tail_backward_bf16x3(const float *g, const void *packed_t, const float *const *masks, float *da1, float *g1,
+                                          float *da0, float *g0, int n_images, int channels, int h, int w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,11 @@ SIGNATURES = {
     "ppo_adam_workspace_bytes": (_sz, []),
     "ppo_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _vp, _vp]),
     "ppo_adam_step_presummed_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _f, _f, _vp, _i, _vp, _vp]),
+    "ppo_impala_stack_tail_bf16x3_packed_bytes": (_sz, []),
+    "ppo_impala_stack_tail_bf16x3_supported": (_i, [_i, _i, _i]),
+    "ppo_impala_stack_tail_pack_bf16x3": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ppo_impala_stack_tail_forward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_impala_stack_tail_backward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_mlp_supported": (_i, [_i, _i, _i]),
     "ppo_mlp_forward_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ppo_mlp_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
