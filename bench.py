@@ -43,6 +43,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_* dense peak (MI355X_MICROARCH.md, Matrix cores)
+# the opt-in split-bf16 launches (--precision low|medium): three bf16 MFMAs per product, so their algorithmic FLOP/s are
+# bounded by a third of the dense bf16 MFMA peak (~2.5 PFLOP/s: v_mfma_f32_16x16x32_bf16, 16 cycles per 16x16x32)
+MFMA_BF16X3_PEAK_TFLOPS = 2516.6 / 3
 SCAN_BYTES_PER_ELEM = 17      # fused adv+returns scan: read r4+v4+done1, write adv4+ret4
 FWD_MFLOP_PER_SAMPLE = 108.4  # IMPALA forward at 4x84x84
 # HBM bytes per launch of the roofline kernel from rocprofv3 --pmc passes over THIS command (tools/pmc_bench.sh
@@ -88,6 +91,10 @@ def parse():
     p.add_argument("--tvf-only", action="store_true", help="only the tvf_returns section (timing / rocprofv3 passes)")
     p.add_argument("--tvf-heads", type=int, default=108, help="K = V of the tvf_returns section")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL)")
+    p.add_argument("--precision", default="high", choices=["low", "medium", "high"],
+                   help="high (default, THE benchmark): exact float32 everywhere.  low / medium: the reference's flag "
+                        "(train.py:166-178 allows TF32 there) - the 32-channel residual blocks run as split-bf16 launches "
+                        "(3 bf16 MFMAs per product); the line's dtype says so and it is never the headline")
     p.add_argument("--no-affinity", action="store_true",
                    help="do not pin the rank (and its env threads) to the cores of its GPU's NUMA node (ppo_amd/affinity.py)")
     p.add_argument("--wall-limit", type=float, default=1500.0,
@@ -355,6 +362,8 @@ def _batch_of(fn, a):
         return a[-4]
     if fn == "ppo_impala_stack_chain_split_forward_f32":
         return a[8]
+    if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3"):
+        return a[7]
     if fn in ("ppo_dense_heads_forward_f32", "ppo_dense_heads_act_forward_f32"):
         return a[9]
     if fn == "ppo_conv3x3_block_forward_packed_f32":
@@ -388,6 +397,10 @@ def _describe_call(fn, a):
     if fn == "ppo_impala_stack_tail_forward_f32":
         n, c, h, w = a[7:11]
         return f"stack blocks fwd (4 conv) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
+    if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3"):
+        n, c, h, w = a[7:11]
+        kind = "fwd" if "forward" in fn else "bwd-data"
+        return f"stack blocks {kind} (4 conv, 3 x bf16 MFMA) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
     if fn == "ppo_impala_stack_tail_backward_f32":
         n, c, h, w = a[7:11]
         return f"stack blocks bwd-data (4 conv) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
@@ -502,7 +515,10 @@ class KernelTable:
                  "avg_us": round(1e3 * ms / len(row["events"]), 2)}
             if row["flops"]:
                 r.update(bound="mfma", achieved=round(row["flops"] / (ms * 1e-3) / 1e12, 2), unit="TFLOP/s")
-                r["frac"] = round(r["achieved"] / MFMA_F32_PEAK_TFLOPS, 4)
+                peak = MFMA_BF16X3_PEAK_TFLOPS if "bf16" in label else MFMA_F32_PEAK_TFLOPS
+                r["frac"] = round(r["achieved"] / peak, 4)
+                if "bf16" in label:
+                    r["peak"] = round(peak, 1)
             elif row["bytes"]:
                 r.update(bound="hbm", achieved=round(row["bytes"] / (ms * 1e-3) / 1e9, 1), unit="GB/s")
                 r["frac"] = round(r["achieved"] / HBM_PEAK_GBPS, 4)
@@ -778,7 +794,7 @@ def main():
     mb = 256
     args.setup([f"--agents={A}", f"--n_steps={N}", *cfg["flags"], "--seed=1", f"--device=cuda:{local}",
                 f"--policy_opt_mini_batch_size={mb * world}", "--disable_logging=True", "--upload_batch=True",
-                "--env_reward_normalization=off"])
+                "--env_reward_normalization=off", f"--precision={a.precision}"])
     torch.manual_seed(1)
     np.random.seed(1 + rank)
     if a.config == "humanoid_tvf":
@@ -801,7 +817,7 @@ def main():
         assert tuple(obs_shape) == tuple(cfg["obs"]) and n_actions == cfg["actions"], (obs_shape, n_actions)
         model = models.TVFModel(encoder="impala", input_dims=obs_shape, actions=n_actions, device=f"cuda:{local}",
                                 architecture="single", hidden_units=args.model.hidden_units,
-                                head_scale=args.model.head_scale, head_bias=args.model.head_bias)
+                                head_scale=args.model.head_scale, head_bias=args.model.head_bias, precision=args.precision)
         runner = rollout.Runner(model, logger.Logger(quiet=True))
         runner.vec_env = envs.create_envs_classic(rank=rank, world=world)
     runner.reset()
@@ -817,6 +833,9 @@ def main():
     # (n == A / 2) are timed separately: at half batch the one-workgroup-per-image kernels fill half the chip.
     # The other configs take their roofline kernel from the per-kernel table below (its largest row).
     geo = {"pong": (32, 21, 21)}.get(a.config)
+    split = bool(getattr(model.policy_net, "split_bf16", False))
+    if split:
+        geo = None  # the probed launches do not run in split mode: the per-kernel table's largest row is the roofline kernel
 
     def probe_match_n(n_want):
         def match(fn_name, c):
@@ -939,7 +958,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not split else "f32 + bf16x3 (opt-in --precision=%s: the 32-channel residual blocks, forward and "
+                                         "backward-data, as 3 bf16 MFMAs per product with f32 accumulation; everything else f32)" % a.precision,
         "data": "synthetic",
         "config": {"workload": f"{a.config}: PPO iteration, {A} envs/GPU x {N} steps, obs {tuple(obs_shape)} {obs_kind}, "
                                f"{n_actions} actions, {net_kind} ({model.model_size()} params), "
@@ -989,7 +1009,7 @@ def main():
             top = next((r_ for r_ in table["rows"] if "frac" in r_), None)
             if top is not None:
                 out["roofline"] = {"bound": top["bound"], "achieved": top["achieved"],
-                                   "peak": MFMA_F32_PEAK_TFLOPS if top["bound"] == "mfma" else HBM_PEAK_GBPS,
+                                   "peak": top.get("peak", MFMA_F32_PEAK_TFLOPS) if top["bound"] == "mfma" else HBM_PEAK_GBPS,
                                    "unit": top["unit"], "frac": top["frac"], "traffic": None,
                                    "kernel": top["kernel"] + " (largest roofline-bound share of kernel time, "
                                              f"{top['share']:.1%}; per-launch HIP events of the extra iteration)",

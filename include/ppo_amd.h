@@ -632,9 +632,17 @@ int ppo_mlp_train_f32(const float *x, const ppo_mlp_net *net, const ppo_mlp_grad
  *   ppo_impala_stack_tail_backward_bf16x3  as ppo_impala_stack_tail_backward_f32 (masks: a1, q0, a0, p)
  * 32 channels at 21x21 or 11x11 (ppo_impala_stack_tail_bf16x3_supported).
  */
+typedef struct ppo_split_pack_job {
+    const float *weights[4]; /* raw [32, 32, 3, 3] each, in the order the kernel walks its layers */
+    void *packed;            /* ppo_impala_stack_tail_bf16x3_packed_bytes() bytes, 16-byte aligned */
+    int channels;            /* 32 */
+    int transposed;          /* 0 forward, 1 backward-data */
+} ppo_split_pack_job;
 size_t ppo_impala_stack_tail_bf16x3_packed_bytes(void);
 int ppo_impala_stack_tail_bf16x3_supported(int channels, int h, int w);
 int ppo_impala_stack_tail_pack_bf16x3(const float *const *weights, void *packed, int channels, int transposed, void *stream);
+/* several packings in one launch (host table of at most 8 jobs): what follows every optimiser step in split mode */
+int ppo_impala_stack_tail_pack_bf16x3_jobs(const ppo_split_pack_job *jobs /* host */, int n_jobs, void *stream);
 int ppo_impala_stack_tail_forward_bf16x3(const float *in, const void *packed, const float *const *biases, float *a0, float *q0,
                                          float *a1, float *q1, int n_images, int channels, int h, int w, void *stream);
 int ppo_impala_stack_tail_backward_bf16x3(const float *g, const void *packed_t, const float *const *masks, float *da1, float *g1,

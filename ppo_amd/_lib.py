@@ -102,6 +102,7 @@ SIGNATURES = {
     "ppo_impala_stack_tail_bf16x3_packed_bytes": (_sz, []),
     "ppo_impala_stack_tail_bf16x3_supported": (_i, [_i, _i, _i]),
     "ppo_impala_stack_tail_pack_bf16x3": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ppo_impala_stack_tail_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),
     "ppo_impala_stack_tail_forward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_impala_stack_tail_backward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_mlp_supported": (_i, [_i, _i, _i]),
@@ -114,6 +115,12 @@ SIGNATURES = {
 class PackJob(ctypes.Structure):
     """ppo_pack_job (include/ppo_amd.h)."""
     _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+                ("transposed", ctypes.c_int)]
+
+
+class SplitPackJob(ctypes.Structure):
+    """ppo_split_pack_job (include/ppo_amd.h)."""
+    _fields_ = [("weights", ctypes.c_void_p * 4), ("packed", ctypes.c_void_p), ("channels", ctypes.c_int),
                 ("transposed", ctypes.c_int)]
 
 

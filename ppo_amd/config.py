@@ -282,7 +282,10 @@ class Config:
         a("--checkpoint_compression", type=str2bool, nargs="?", const=True, default=True)
         a("--workers", type=int, default=self.workers)
         a("--threads", type=int, default=self.threads)
-        a("--precision", type=str, default=self.precision, help="[low|medium|high]; all run exact fp32 here")
+        a("--precision", type=str, default=self.precision,
+          help="[low|medium|high] (train.py:166-178): high = exact float32 everywhere; low / medium also allow the "
+               "split-bf16 launches (3 bf16 MFMAs per product, ~16-bit products) where they exist - the residual blocks of "
+               "the IMPALA encoder's 32-channel stacks")
         a("--use_intrinsic_rewards", type=str2bool, nargs="?", const=True, default=False)
         a("--sync_envs", type=str2bool, nargs="?", const=True, default=False)
         a("--override_reward_normalization_gamma", type=float, default=None)

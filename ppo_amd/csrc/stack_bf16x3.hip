@@ -194,13 +194,22 @@ __global__ __launch_bounds__(NW * 2 * 64) void stack_tail_bf16x3_kernel(SplitTai
 // weights [cout 32][cin 32][3][3] float32 -> A fragments: lane (row = l & 15, k = 8 (l >> 4) + j).  Forward: row = output
 // channel, k = input channel, tap as stored.  Transposed (backward-data): row = INPUT channel, k = output channel, tap
 // flipped - dX[i] = sum_{o, taps} W[o][i][2 - ky][2 - kx] dY[o] is a forward convolution with those weights.
-__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *w0, const float *w1, const float *w2, const float *w3,
-                                                          __bf16 *packed, int transposed)
+constexpr int kMaxSplitJobs = 8;
+struct SplitPackJobs {
+    const float *w[kMaxSplitJobs][4];
+    __bf16 *packed[kMaxSplitJobs];
+    int transposed[kMaxSplitJobs];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const SplitPackJobs jobs)
 {
+    const int job = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (layer, ng, tap, lane)
-    if (i >= 4 * 2 * 9 * 64) return;
+    if (i >= 4 * 2 * 9 * 64 || job >= jobs.n) return;
     const int lane = i & 63, t = (i >> 6) % 9, ng = (i / (64 * 9)) & 1, layer = i / (64 * 9 * 2);
-    const float *w = layer == 0 ? w0 : (layer == 1 ? w1 : (layer == 2 ? w2 : w3));
+    const float *w = jobs.w[job][layer];
+    __bf16 *packed = jobs.packed[job];
+    const int transposed = jobs.transposed[job];
     const int row = ng * 16 + (lane & 15), k0 = 8 * (lane >> 4);
     __bf16 *hi = packed + (((size_t)(layer * 2 + ng) * 9 + t) * 2 + 0) * 64 * 8 + lane * 8;
     __bf16 *lo = packed + (((size_t)(layer * 2 + ng) * 9 + t) * 2 + 1) * 64 * 8 + lane * 8;
@@ -260,16 +269,34 @@ extern "C" int ppo_impala_stack_tail_bf16x3_supported(int channels, int h, int w
     return channels == 32 && ((h == 21 && w == 21) || (h == 11 && w == 11));
 }
 
+extern "C" int ppo_impala_stack_tail_pack_bf16x3_jobs(const ppo_split_pack_job *jobs, int n_jobs, void *stream)
+{
+    using namespace ppo;
+    if (n_jobs < 0 || n_jobs > kMaxSplitJobs) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: 0 .. %d jobs", kMaxSplitJobs);
+    if (n_jobs == 0) return PPO_OK;
+    if (!jobs) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: null job table");
+    SplitPackJobs t{};
+    t.n = n_jobs;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (jobs[j].channels != 32) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: 32 channels only");
+        if (!jobs[j].packed || !aligned(jobs[j].packed, 16)) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: null or misaligned packed buffer");
+        for (int l = 0; l < 4; ++l) {
+            if (!jobs[j].weights[l]) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: null weights");
+            t.w[j][l] = jobs[j].weights[l];
+        }
+        t.packed[j] = static_cast<__bf16 *>(jobs[j].packed);
+        t.transposed[j] = jobs[j].transposed;
+    }
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((4 * 2 * 9 * 64 + 255) / 256, n_jobs), dim3(256), 0, as_stream(stream), t);
+    return check_launch("pack_bf16x3_kernel");
+}
+
 extern "C" int ppo_impala_stack_tail_pack_bf16x3(const float *const *weights, void *packed, int channels, int transposed,
                                                  void *stream)
 {
-    using namespace ppo;
-    if (channels != 32) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3: 32 channels only");
-    if (!weights || !packed || !weights[0] || !weights[1] || !weights[2] || !weights[3] || !aligned(packed, 16))
-        return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3: null or misaligned pointer");
-    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((4 * 2 * 9 * 64 + 255) / 256), dim3(256), 0, as_stream(stream), weights[0],
-                       weights[1], weights[2], weights[3], static_cast<__bf16 *>(packed), transposed);
-    return check_launch("pack_bf16x3_kernel");
+    if (!weights) return ppo::fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3: null pointer");
+    ppo_split_pack_job job{{weights[0], weights[1], weights[2], weights[3]}, packed, channels, transposed};
+    return ppo_impala_stack_tail_pack_bf16x3_jobs(&job, 1, stream);
 }
 
 extern "C" int ppo_impala_stack_tail_forward_bf16x3(const float *in, const void *packed, const float *const *biases, float *a0,

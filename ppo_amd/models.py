@@ -325,8 +325,10 @@ class DualHeadNet:
     def __init__(self, encoder: str, input_dims, n_actions: int, hidden_units: int = 256,
                  activation_fn: str = "relu", tvf_fixed_head_horizons=None, tvf_feature_sparsity: float = 0.0,
                  tvf_feature_window: int = -1, head_scale: float = 1.0, value_head_names=("ext",),
-                 head_bias: bool = False, device="cuda", **encoder_args):
+                 head_bias: bool = False, device="cuda", precision: str = "high", **encoder_args):
         encoder = encoder.lower()
+        if precision not in ("low", "medium", "high"):
+            raise ValueError(f"Invalid precision mode {precision}")
         if encoder not in ("impala", "mlp"):
             raise NotImplementedError(f"encoder '{encoder}' has no HIP path (impala | mlp)")
         if activation_fn not in ("relu", "tanh"):
@@ -374,6 +376,7 @@ class DualHeadNet:
         self._plans = {}   # (tag, batch, dtype) -> recorded inference launch list
         self.use_plans = True  # False: every inference launch goes through _call (bench.py's per-kernel table brackets it)
         self._build_packed_weights()
+        self._build_split_bf16(precision)
         self._build_mlp_fused()
         self._adam_step = 0
         self.exp_avg = None
@@ -424,6 +427,33 @@ class DualHeadNet:
             self.g_b_heads = self.grad[o:o + self.nh]
         else:
             self.b_heads = self.g_b_heads = None
+
+    def _build_split_bf16(self, precision):
+        """--precision=low|medium (rl train.py:166-178 lets cuDNN use TF32 there): the residual blocks of the 32-channel
+        stacks run as split-bf16 launches (csrc/stack_bf16x3.hip: three bf16 MFMAs per product, float32 accumulation,
+        ~16-bit products; forward and backward-data).  `high` - the default of this class, of bench.py and of every
+        parity test - is exact float32 everywhere.  Buffers: per such stack the forward and the transposed packing of
+        its four block convolutions, refreshed by ONE launch behind the float32 re-pack."""
+        self.precision = precision
+        self.split_bf16, self._pk16, self._split_jobs = False, {}, None
+        if precision == "high" or self.encoder_kind != "impala" or self.spec.n_block != 2:
+            return
+        jobs = []
+        nbytes = int(self.lib.ppo_impala_stack_tail_bf16x3_packed_bytes())
+        for si, (_cin, cout, _h, _w, ho, wo) in enumerate(self.spec.stacks):
+            if not self.lib.ppo_impala_stack_tail_bf16x3_supported(cout, ho, wo):
+                continue
+            for tr, order in ((0, ((0, 0), (0, 1), (1, 0), (1, 1))), (1, ((1, 1), (1, 0), (0, 1), (0, 0)))):
+                buf = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+                self._pk16[(si, tr)] = buf
+                ws = [self.params[f"encoder.stacks.{si}.blocks.{bi}.conv{ci}.weight"].data_ptr() for bi, ci in order]
+                jobs.append(_lib.SplitPackJob((ctypes.c_void_p * 4)(*ws), buf.data_ptr(), cout, tr))
+            names = [f"encoder.stacks.{si}.blocks.{bi}.conv{ci}" for bi in range(2) for ci in range(2)]
+            self._pk16[(si, "bias")] = (ctypes.c_void_p * 4)(*[self.params[n + ".bias"].data_ptr() for n in names])
+        if jobs:
+            self._split_jobs = (_lib.SplitPackJob * len(jobs))(*jobs)
+            self.split_bf16 = True
+            self._packed_dirty = True
 
     def _build_mlp_fused(self):
         """The pointer tables of the fused MLP launches (the flat buffers never move)."""
@@ -566,14 +596,17 @@ class DualHeadNet:
 
     def mark_weights_changed(self):
         """Call after writing convolution weights other than through adam_step / load_state_dict."""
-        self._packed_dirty = self._pack_table is not None
+        self._packed_dirty = self._pack_table is not None or getattr(self, "split_bf16", False)
 
     def _refresh_packed(self):
         if self._packed_dirty:
             self._packed_dirty = False
             rec, self._rec = self._rec, None  # never part of a recorded forward: the refresh is conditional
             try:
-                self._call("ppo_conv3x3_pack_weights_f32", ctypes.addressof(self._pack_table), len(self._pack_table))
+                if self._pack_table is not None:
+                    self._call("ppo_conv3x3_pack_weights_f32", ctypes.addressof(self._pack_table), len(self._pack_table))
+                if self.split_bf16:
+                    self._call("ppo_impala_stack_tail_pack_bf16x3_jobs", ctypes.addressof(self._split_jobs), len(self._split_jobs))
             finally:
                 self._rec = rec
 
@@ -732,8 +765,8 @@ class DualHeadNet:
         """Host arrays of the five packed-weight / bias pointers (firstconv + the four block convolutions) of stack
         si for the whole-stack kernel, or None when it does not apply."""
         if not (FUSE_STACK_FULL and FUSE_STACK_TAIL) or self.spec.n_block != 2 or cin != cout \
-                or not self.lib.ppo_impala_stack_full_supported(cout, h, w):
-            return None
+                or not self.lib.ppo_impala_stack_full_supported(cout, h, w) or self.split_bf16:
+            return None  # (split mode: the blocks of the 32-channel stacks have their own launches)
         cached = self._tail_ptrs.get(("full", si))
         if cached is None:
             names = [f"encoder.stacks.{si}.firstconv"] + [f"encoder.stacks.{si}.blocks.{bi}.conv{ci}"
@@ -875,6 +908,16 @@ class DualHeadNet:
                 self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
             acts[f"in{si}"], acts[f"idx{si}"] = cur, idx
             q = p
+            if self.split_bf16 and (si, 0) in self._pk16:
+                # --precision=low|medium: this stack's residual blocks as the split-bf16 launch
+                names = [f"{tag}a{si}_0", f"{tag}q{si}_0", f"{tag}a{si}_1", f"{tag}q{si}_1"]
+                a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
+                self._call("ppo_impala_stack_tail_forward_bf16x3", _p(p), _p(self._pk16[(si, 0)]), self._pk16[(si, "bias")],
+                           _p(a0) if train else None, _p(q0) if train else None, _p(a1) if train else None, _p(q1), B, cout,
+                           ho, wo)
+                acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"] = p, a0, q0, a1
+                cur, cur_mode = q1, IN_NONE
+                continue
             tail = self._stack_tail_ptrs(si, cout, ho, wo, B)
             if tail is not None:
                 names = [f"{tag}a{si}_0", f"{tag}q{si}_0", f"{tag}a{si}_1", f"{tag}q{si}_1"]
@@ -1158,6 +1201,9 @@ class DualHeadNet:
                 g = g_prev
                 continue
             tail_w = self._stack_tail_bwd_ptrs(si, cout, ho, wo)
+            split = self.split_bf16 and (si, 1) in self._pk16
+            if split:
+                tail_w = True  # the gated transposed chain of this stack's blocks as the split-bf16 launch
             if tail_w is not None:
                 # the four backward-data convolutions of the stack's blocks in one launch (csrc/stack_fused.hip)
                 b0, b1 = f"encoder.stacks.{si}.blocks.0", f"encoder.stacks.{si}.blocks.1"
@@ -1165,8 +1211,12 @@ class DualHeadNet:
                 da1, g1, da0, g0 = (self._buf(nm, (B, cout, ho, wo)) for nm in
                                     (f"g{si}_1_da", f"g{si}_1_in", f"g{si}_0_da", f"g{si}_0_in"))
                 masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p_in.data_ptr())
-                self._call("ppo_impala_stack_tail_backward_f32", _p(g), tail_w, masks, _p(da1), _p(g1), _p(da0), _p(g0),
-                           B, cout, ho, wo)
+                if split:
+                    self._call("ppo_impala_stack_tail_backward_bf16x3", _p(g), _p(self._pk16[(si, 1)]), masks, _p(da1), _p(g1),
+                               _p(da0), _p(g0), B, cout, ho, wo)
+                else:
+                    self._call("ppo_impala_stack_tail_backward_f32", _p(g), tail_w, masks, _p(da1), _p(g1), _p(da0), _p(g0),
+                               B, cout, ho, wo)
                 wgrad_blocks([(a1, g, b1 + ".conv1"), (q0, da1, b1 + ".conv0"), (a0, g1, b0 + ".conv1"),
                               (p_in, da0, b0 + ".conv0")], B, cout, ho, wo)
                 g = g0
@@ -1493,7 +1543,7 @@ class TVFModel:
                  freeze_observation_normalization=False, tvf_fixed_head_horizons=None, tvf_fixed_head_weights=None,
                  tvf_feature_sparsity: float = 0.0, tvf_feature_window: int = -1, head_scale: float = 1.0,
                  value_head_names=("ext",), norm_eps: float = 1e-5, head_bias: bool = False,
-                 observation_scaling: str = "scaled"):
+                 observation_scaling: str = "scaled", precision: str = "high"):
         if architecture not in ("single", "dual"):
             raise Exception("Invalid architecture, use [dual|single]")
         if use_rnd:
@@ -1522,7 +1572,7 @@ class TVFModel:
                                activation_fn=encoder_activation_fn, tvf_fixed_head_horizons=tvf_fixed_head_horizons,
                                tvf_feature_sparsity=tvf_feature_sparsity, tvf_feature_window=tvf_feature_window,
                                head_scale=head_scale, value_head_names=value_head_names, head_bias=head_bias,
-                               device=device, **(encoder_args or {}))
+                               device=device, precision=precision, **(encoder_args or {}))
 
         self.policy_net = make_net()
         self.value_net = make_net() if architecture == "dual" else self.policy_net

@@ -104,3 +104,76 @@ def test_split_bf16_training_forward_and_backward_match_the_exact_kernels(hw, st
         err = float((got - want).abs().max()) / float(want.abs().max())
         assert err <= 1e-4, (name, err)
         assert not torch.equal(got, want), name  # (the split path ran, not the exact one)
+
+
+def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches():
+    """`--precision=medium` (DualHeadNet(precision=...)): the same reference fixtures as the exact path - forward within
+    1e-4 of the reference's largest output, greedy actions index-exact on the 256-observation fixture (both heads), every
+    parameter gradient of one PPO minibatch within 1e-3 of its largest entry - with the split launches really taken,
+    forward and backward, and `high` (the default) untouched by any of it."""
+    import hashlib
+    import json
+    import os
+    here = os.path.dirname(__file__)
+    g = np.load(os.path.join(here, "golden", "model_golden.npz"))
+    meta = json.load(open(os.path.join(here, "golden", "model_golden.json")))
+    z = np.load(os.path.join(here, "golden", "greedy_golden.npz"))
+    jm = json.load(open(os.path.join(here, "golden", "greedy_golden.json")))
+
+    def build(precision):
+        torch.manual_seed(meta["seed"])
+        net = models.DualHeadNet("impala", tuple(meta["input_dims"]), meta["n_actions"], hidden_units=meta["hidden_units"],
+                                 head_scale=meta["head_scale"], head_bias=meta["head_bias"], device="cuda", precision=precision)
+        calls = []
+        orig = net._call
+        net._call = lambda fn, *a: (calls.append(fn), orig(fn, *a))[1]
+        return net, calls
+
+    hi, calls_hi = build("high")
+    md, calls_md = build("medium")
+    assert md.split_bf16 and not hi.split_bf16 and torch.equal(hi.flat, md.flat)
+    x = torch.from_numpy(g["fwd_x"]).cuda()
+    o_hi, o_md = hi.forward(x), md.forward(x)
+    for k in ("raw_policy", "log_policy", "value", "advantage"):
+        ref = g[f"fwd_{k}"]
+        for name, o in (("high", o_hi), ("medium", o_md)):
+            err = float(np.abs(o[k].cpu().numpy().reshape(ref.shape) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+            assert err <= 1e-4, (name, k, err)
+    assert calls_md.count("ppo_impala_stack_tail_forward_bf16x3") == 2 and "ppo_impala_stack_tail_forward_bf16x3" not in calls_hi
+    assert not torch.equal(o_hi["raw_policy"], o_md["raw_policy"])
+    # greedy actions on the 256-observation fixture, fresh head and wide head
+    tag = "c2"
+    xs = np.random.default_rng(jm["obs_seed"][tag]).integers(0, 256, size=(jm["batch"], *jm["shapes"][tag][0]), dtype=np.uint8)
+    assert hashlib.sha256(xs.tobytes()).hexdigest() == jm["obs_sha256"][tag]
+    xd = torch.from_numpy(xs).cuda()
+    for prefix in ("", "wide_"):
+        if prefix:
+            md.params["policy_head.weight"].copy_(torch.from_numpy(z[f"{tag}_wide_head_weight"]).cuda())
+            md.params["policy_head.bias"].copy_(torch.from_numpy(z[f"{tag}_wide_head_bias"]).cuda())
+        got = md.forward(xd, policy_temperature=0.0)["argmax_policy"].argmax(1).cpu().numpy()
+        want, margin = z[f"{tag}_{prefix}greedy_actions"], z[f"{tag}_{prefix}logit_margin"]
+        decided = margin > 1e-5
+        assert np.array_equal(got[decided], want[decided]), prefix
+    md.params["policy_head.weight"].copy_(hi.params["policy_head.weight"])
+    md.params["policy_head.bias"].copy_(hi.params["policy_head.bias"])
+    # one PPO minibatch: every gradient of the split path against the exact path's (itself pinned to the reference's)
+    B = x.shape[0]
+    rng = np.random.default_rng(0)
+    actions = torch.from_numpy(rng.integers(0, meta["n_actions"], B).astype(np.int32)).cuda()
+    adv = torch.from_numpy(rng.normal(size=B).astype(np.float32)).cuda()
+    ret = torch.from_numpy(rng.normal(size=(B, 1)).astype(np.float32)).cuda()
+    old_lp = o_hi["log_policy"].clone()
+    old_pac = (old_lp.gather(1, actions.long()[:, None])[:, 0] - 0.1).contiguous()
+    grads = {}
+    for name, net in (("high", hi), ("medium", md)):
+        net.grad.zero_()
+        net.ppo_minibatch(x, actions, old_pac, old_lp, adv, ret)
+        torch.cuda.synchronize()
+        grads[name] = {k: v.clone() for k, v in net.grads.items()}
+    assert calls_md.count("ppo_impala_stack_tail_backward_bf16x3") == 2 and "ppo_impala_stack_tail_backward_bf16x3" not in calls_hi
+    worst = 0.0
+    for k, gh in grads["high"].items():
+        scale = float(gh.abs().max())
+        if scale > 0:
+            worst = max(worst, float((grads["medium"][k] - gh).abs().max()) / scale)
+    assert 0 < worst <= 1e-3, worst

@@ -40,7 +40,10 @@ def make_model(log):
         head_bias=args.model.head_bias, value_head_names=("ext",),
         observation_normalization=args.observation_normalization,
         freeze_observation_normalization=args.freeze_observation_normalization,
-        norm_eps=args.observation_normalization_epsilon)
+        norm_eps=args.observation_normalization_epsilon,
+        # train.py:166-178: low / medium let the GPU use reduced-precision convolution arithmetic (there TF32, here the
+        # split-bf16 launches of the 32-channel stacks); high is exact float32 everywhere
+        precision=args.precision)
 
 
 def get_previous_experiment_guid(experiment_path, run_name):
