@@ -549,7 +549,8 @@ struct ActTail {
     ActOut out;
 };
 
-template <int KPL, int NA>
+// NHT: head columns handled (16 or 32: the 15-action suites have 2 * 15 + 1 = 31 heads; their head weights take 128 registers)
+template <int KPL, int NA, int NHT>
 __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__restrict__ partial, int split, int M, int H,
                                                             const float *__restrict__ bias, float *__restrict__ h,
                                                             const float *__restrict__ Wh, const float *__restrict__ bh, int NH,
@@ -563,11 +564,11 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     int off[KPL];  // element offset of (m, k) inside a slice, or -1
 #pragma unroll
     for (int i = 0; i < KPL; ++i) off[i] = lane + 64 * i < H ? m * H + lane + 64 * i : -1;
-    // the head weights of this lane's columns are requested first (NH <= 16 columns, one pass): they depend on nothing
+    // the head weights of this lane's columns are requested first (NH <= NHT columns, one pass): they depend on nothing
     // and arrive under the slice sums
-    float bv[16][KPL];
+    float bv[NHT][KPL];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NHT; ++j) {
         const int row = min(j, NH - 1) * H;
 #pragma unroll
         for (int i = 0; i < KPL; ++i) bv[j][i] = buffer_f32(wb, off[i] < 0 ? kOutside : (row + lane + 64 * i) * 4);
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     }
     float out = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NHT; ++j) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < KPL; ++i) acc = fmaf(relu_h ? fmaxf(hv[i], 0.f) : hv[i], bv[j][i], acc);
@@ -823,19 +824,26 @@ int gemm_dispatch(const float *A, int64_t a_sm, int64_t a_sk, int relu_a, const 
     int rc = check_launch("gemm_f32_kernel");
     if (rc) return rc;
     if (split > 1) {
-        if (tail && !mask && ldc == N && N <= 256 && tail->NH <= 16 && (int64_t)split * M * N * 4 < (int64_t)kBufferBytes) {
-#define PPO_FINALIZE(NA, ACT)                                                                                          \
-    hipLaunchKernelGGL((finalize_heads_kernel<4, NA>), dim3((M + 3) / 4), dim3(256), 0, st,                            \
+        if (tail && !mask && ldc == N && N <= 256 && tail->NH <= 32 && (int64_t)split * M * N * 4 < (int64_t)kBufferBytes) {
+#define PPO_FINALIZE(NA, NHT, ACT)                                                                                     \
+    hipLaunchKernelGGL((finalize_heads_kernel<4, NA, NHT>), dim3((M + 3) / 4), dim3(256), 0, st,                       \
                        static_cast<const float *>(workspace), split, M, N, bias, C, tail->Wh, tail->bh, tail->NH,      \
                        tail->relu_h, tail->heads, ACT)
             tail->act_fused = tail->act != nullptr;
+            const bool wide = tail->NH > 16;  // (a 512-row launch of the 31-head net made four launches before: 90 us bracketed)
+#define PPO_FIN2(NA, ACT)                       \
+    do {                                        \
+        if (wide) PPO_FINALIZE(NA, 32, ACT);    \
+        else PPO_FINALIZE(NA, 16, ACT);         \
+    } while (0)
             switch (tail->act ? tail->act_n : 0) {  // the action counts of the benchmark suites; others sample in their own launch
-                case 4: PPO_FINALIZE(4, *tail->act); break;
-                case 6: PPO_FINALIZE(6, *tail->act); break;
-                case 15: PPO_FINALIZE(15, *tail->act); break;
-                case 18: PPO_FINALIZE(18, *tail->act); break;
-                default: PPO_FINALIZE(0, ActTail{}); tail->act_fused = false;
+                case 4: PPO_FIN2(4, *tail->act); break;
+                case 6: PPO_FIN2(6, *tail->act); break;
+                case 15: PPO_FIN2(15, *tail->act); break;
+                case 18: PPO_FIN2(18, *tail->act); break;
+                default: PPO_FIN2(0, ActTail{}); tail->act_fused = false;
             }
+#undef PPO_FIN2
 #undef PPO_FINALIZE
             tail->fused = true;
             return check_launch("finalize_heads_kernel");

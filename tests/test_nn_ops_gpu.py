@@ -268,7 +268,7 @@ def test_dense_heads_forward_is_bitwise_the_two_products(bsz):
     assert _close(o_ref, F.relu(F.relu(x) @ W.t() + b) @ Wh.t() + bh, 1e-4)
 
 
-@pytest.mark.parametrize("bsz,nA", [(128, 6), (100, 4), (1, 15), (256, 18), (37, 7)])
+@pytest.mark.parametrize("bsz,nA", [(128, 6), (100, 4), (1, 15), (256, 18), (37, 7), (512, 15)])
 @pytest.mark.parametrize("use_ws", [True, False])
 def test_dense_heads_with_action_sampling_is_bitwise_the_separate_launches(bsz, nA, use_ws):
     """ppo_dense_heads_act_forward_f32 (the rollout's action step on the finished head row, in the finalize launch) against
@@ -280,6 +280,8 @@ def test_dense_heads_with_action_sampling_is_bitwise_the_separate_launches(bsz, 
     g = torch.Generator().manual_seed(bsz * 31 + nA)
     K, H, vh = 3872, 256, 2
     NH = nA + vh + 3
+    if bsz == 512:  # BASELINE configs[2]'s rollout group: 2048-wide dense layer, 2 * 15 + 1 = 31 head columns (the 32-column
+        K, NH = 2048, 2 * nA + 1  # form of the finalize launch; before round 4 this shape took four launches)
     x = torch.randn(bsz, K, generator=g).to(DEV)
     W = (torch.randn(H, K, generator=g) * 0.02).to(DEV)
     b = torch.randn(H, generator=g).to(DEV)
