@@ -150,6 +150,16 @@ int ppo_conv3x3_backward_data_packed_f32(const float *dy, const float *packed, c
 int ppo_conv3x3_pool_forward_packed_f32(const void *in, int in_mode, const float *packed, const float *bias,
                                         float *out, uint8_t *argmax, int n, int cin, int cout, int h, int w,
                                         void *stream);
+/* The same launch reading image i of the batch at in[index[i]] (uint8 observations; index nullable): the minibatch gather of
+ * rl/rollout.py:2349-2372 (host fancy-indexing + upload there) happens in the first convolution's own loads instead of in a
+ * gather launch and a second copy of the observations.  ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32 is the
+ * matching form of the first layer's weight gradient. */
+int ppo_conv3x3_pool_forward_packed_indexed_f32(const void *in, const int32_t *index, int in_mode, const float *packed,
+                                                const float *bias, float *out, uint8_t *argmax, int n, int cin, int cout,
+                                                int h, int w, void *stream);
+int ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32(const void *in, const int32_t *index, int in_mode, const float *g,
+                                                         const uint8_t *argmax, void *workspace, size_t workspace_bytes,
+                                                         int n, int cin, int cout, int h, int w, int *n_slabs, void *stream);
 
 /*
  * One residual block, q' = q + conv1(relu(conv0(relu(q)))) (rl/impala.py:66-84), as ONE launch for inference on small

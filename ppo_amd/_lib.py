@@ -71,11 +71,13 @@ SIGNATURES = {
     "ppo_conv3x3_forward_packed_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_backward_data_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_pool_forward_packed_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_pool_forward_packed_indexed_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_block_supported": (_i, [_i, _i, _i]),
     "ppo_conv3x3_block_forward_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_backward_weight_slabs_f32": (_i, [_vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_backward_weight_pooled_supported": (_i, [_i, _i, _i, _i]),
     "ppo_conv3x3_backward_weight_slabs_pooled_f32": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_backward_weight_slabs_batch_f32": (_i, [_vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_wgrad_reduce_f32": (_i, [_vp, _i, _vp]),
     "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),

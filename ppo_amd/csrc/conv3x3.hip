@@ -61,6 +61,9 @@ __device__ unsigned long long ppo_tune_stamps[8 * 8 * 1024];  // [workgroup][wav
 // (ppo_conv3x3_pack_weights_f32) instead of the raw [O][I][3][3] tensor.  Host-side, thread-local, consumed by the
 // launch a few frames down the same call.
 thread_local int t_weights_packed = 0;
+// images of the next conv3x3_pool launch are read through this index (ppo_conv3x3_pool_forward_packed_indexed_f32): the
+// minibatch gather of the observations happens in the first convolution's own loads
+thread_local const int32_t *t_in_index = nullptr;
 
 // Packed A operand of a kernel with (kernel-side) CIN input and COUT output channels: for K step s = tap*CINP/4 + cs
 // and channel tile n, lane (l15, g) holds w(co = n*16 + l15, ci = cs*4 + g, tap); four consecutive steps form one
@@ -656,7 +659,8 @@ struct ConvPoolCfg {
 template <int CIN, int COUT, int H, int W, int PR, int MT, int NW, int IN_MODE, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__restrict__ in_, const float *__restrict__ w,
                                                               const float *__restrict__ bias, float *__restrict__ out,
-                                                              uint8_t *__restrict__ argmax, int n_images)
+                                                              uint8_t *__restrict__ argmax, int n_images,
+                                                              const int32_t *__restrict__ in_index)
 {
     constexpr bool DMA = IN_MODE != IN_U8;
     constexpr int kWaves = NW, kThreads = NW * 64;
@@ -716,8 +720,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     }
 
     const int n_items = n_images * C::NBANDS;
+    // image `img` of the launch is image in_index[img] of the input tensor (the minibatch permutation), or img itself
+    auto src_img = [&](int img) { return in_index ? in_index[img] : img; };
     auto stage = [&](int item, float *dst) {
-        const int img = item / C::NBANDS;
+        const int img = src_img(item / C::NBANDS);
         const int y0 = 2 * (item % C::NBANDS) * PR - 1;  // band row r holds image row y0 + r - 1 = 2*yo0 - 2 + r
         if constexpr (DMA)
             stage_band_chunk_dma<CIN, H, W, C::ROWS, C::PLANE, C::G, kWaves>(static_cast<const float *>(in_), img, y0, dst, tid);
@@ -737,9 +743,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_pool_kernel(const void *__res
     }
     auto prefetch = [&](int item) {
         if constexpr (U8X4)
-            band_u8x4_load<CIN, H, W, C::ROWS, kThreads>(in_, item / C::NBANDS, 2 * (item % C::NBANDS) * PR - 1, tid, raw);
+            band_u8x4_load<CIN, H, W, C::ROWS, kThreads>(in_, src_img(item / C::NBANDS), 2 * (item % C::NBANDS) * PR - 1, tid, raw);
         else if constexpr (!DMA)
-            band_flat_load<CIN, C::CINP, H, W, C::ROWS, IN_MODE, kWaves>(in_, item / C::NBANDS,
+            band_flat_load<CIN, C::CINP, H, W, C::ROWS, IN_MODE, kWaves>(in_, src_img(item / C::NBANDS),
                                                                          2 * (item % C::NBANDS) * PR - 1, tid, raw);
     };
     if (!DMA && (int)blockIdx.x < n_items) prefetch(blockIdx.x);
@@ -931,7 +937,7 @@ int launch_conv_pool_impl(const void *in, const float *w, const float *bias, flo
     const int n_items = n_images * C::NBANDS;
     int grid = 256 * wg_per_cu;
     if (grid > n_items) grid = n_items;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), kLdsBytes, st, in, w, bias, out, argmax, n_images);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), kLdsBytes, st, in, w, bias, out, argmax, n_images, t_in_index);
     return check_launch("conv3x3_pool_kernel");
 }
 
@@ -1027,6 +1033,20 @@ extern "C" int ppo_conv3x3_pool_forward_f32(const void *in, int in_mode, const f
         case IN_U8: return dispatch_conv_pool<IN_U8>(cin, cout, h, w, in, weight, bias, out, argmax, n, st);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_pool_forward_f32: in_mode %d (the stack-first convolution reads raw input)", in_mode);
+}
+
+extern "C" int ppo_conv3x3_pool_forward_packed_indexed_f32(const void *in, const int32_t *index, int in_mode, const float *packed,
+                                                           const float *bias, float *out, uint8_t *argmax, int n, int cin,
+                                                           int cout, int h, int w, void *stream)
+{
+    if (index && in_mode != ppo::IN_U8)
+        return ppo::fail(PPO_E_INVALID, "ppo_conv3x3_pool_forward_packed_indexed_f32: the index applies to uint8 observations");
+    ppo::t_weights_packed = 1;
+    ppo::t_in_index = index;
+    const int rc = ppo_conv3x3_pool_forward_f32(in, in_mode, packed, bias, out, argmax, n, cin, cout, h, w, stream);
+    ppo::t_in_index = nullptr;
+    ppo::t_weights_packed = 0;
+    return rc;
 }
 
 extern "C" size_t ppo_conv3x3_packed_floats(int cin, int cout, int transposed)

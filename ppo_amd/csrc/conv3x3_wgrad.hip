@@ -205,12 +205,16 @@ __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, con
 // Up to kWgradBatch independent problems of one geometry per launch (blockIdx.y picks one): the layers of a stack share
 // their geometry and their gradients are all known once its backward-data pass is through, and one launch of 4 x the
 // workgroups has one ramp and one tail where four launches have four (per-launch constant ~10 us).
+// set by ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32 around its dispatch (see WgradBatch::in_index)
+thread_local const int32_t *t_wgrad_in_index = nullptr;
 constexpr int kWgradBatch = 4;
 struct WgradBatch {
     const void *in[kWgradBatch];
     const float *dy[kWgradBatch];  // DY_POOLED: the POOLED gradient g [n, COUT, H/2, W/2] ...
     float *partial[kWgradBatch];
     const uint8_t *argmax;         // ... and the pooling's argmax (problem 0 only): dy = maxpool_backward(g, argmax)
+    const int32_t *in_index;       // nullable (uint8 input only): image i of the launch is image in_index[i] of `in` - the
+                                   // minibatch permutation, so that the observations need no gathered copy
 };
 
 template <int CIN, int COUT, int H, int W, int TR, int IN_MODE, bool DY_POOLED = false>
@@ -280,7 +284,7 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
             if constexpr (IN_MODE == IN_U8) {
                 // uint8 observations: four pixels per lane (dword load, exact x / 255, 16-byte LDS store)
                 uint32_t raw[FlatU8Map<CIN, W, C::ROWS, kWgradWaves * 64>::Q];
-                band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, img, y0, tid, raw);
+                band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, batch.in_index ? batch.in_index[img] : img, y0, tid, raw);
                 band_u8x4_store<CIN, W, C::ROWS, C::XPLANE, C::G, kWgradWaves * 64>(raw, bx, tid);
             } else {
                 stage_band_chunk_dma<CIN, H, W, C::ROWS, C::XPLANE, C::G, SW>(static_cast<const float *>(in_), img, y0, bx, stid);
@@ -344,7 +348,8 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
         PooledRaw draw[PRE_D ? DM::Q : 1];
         auto prefetch = [&](int item) {
             const int img = item / C::NBANDS, y0 = (item % C::NBANDS) * TR;
-            if constexpr (PRE_X) band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, img, y0, tid, xraw);
+            if constexpr (PRE_X)
+                band_u8x4_load<CIN, H, W, C::ROWS, kWgradWaves * 64>(in_, batch.in_index ? batch.in_index[img] : img, y0, tid, xraw);
             if constexpr (PRE_D) dy_pooled_load<COUT, H, W, TR, kWgradWaves>(dy, batch.argmax, img, y0, tid, draw);
         };
         if ((PRE_X || PRE_D) && (int)blockIdx.x < n_items) prefetch(blockIdx.x);
@@ -618,6 +623,7 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
         batch.partial[0] = workspace;
     }
     batch.argmax = argmax;
+    batch.in_index = IN_MODE == IN_U8 ? t_wgrad_in_index : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid, count), dim3(wgrad_threads<IN_MODE, C::NBANDS, DY_POOLED>()), C::LDS_BYTES, st, batch,
                        n_images);
     int rc = check_launch("conv3x3_wgrad_kernel");
@@ -767,6 +773,20 @@ extern "C" int ppo_conv3x3_backward_weight_slabs_pooled_f32(const void *in, int 
         case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, in, g, nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, nullptr, 1, argmax);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_pooled_f32: in_mode %d has no pooled-gradient kernel", in_mode);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32(const void *in, const int32_t *index, int in_mode,
+                                                                    const float *g, const uint8_t *argmax, void *workspace,
+                                                                    size_t workspace_bytes, int n, int cin, int cout, int h,
+                                                                    int w, int *n_slabs, void *stream)
+{
+    if (index && in_mode != ppo::IN_U8)
+        return ppo::fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32: the index applies to uint8 observations");
+    ppo::t_wgrad_in_index = index;
+    const int rc = ppo_conv3x3_backward_weight_slabs_pooled_f32(in, in_mode, g, argmax, workspace, workspace_bytes, n, cin, cout, h,
+                                                                w, n_slabs, stream);
+    ppo::t_wgrad_in_index = nullptr;
+    return rc;
 }
 
 extern "C" int ppo_conv3x3_backward_weight_pooled_supported(int cin, int cout, int h, int w)

@@ -92,6 +92,9 @@ FUSE_BLOCK = int(os.environ.get("PPO_AMD_FUSE_BLOCK", "1"))
 # statistics; Adam) instead of ~14 launches of 8 - 20 us each.  0 = the op-by-op path (same arithmetic per element up to
 # float32 summation order; tests/test_variants_gpu.py runs both against the reference's fixtures).
 FUSE_MLP = int(os.environ.get("PPO_AMD_FUSE_MLP", "1"))
+# uint8 image minibatches are read out of the whole rollout batch through the permutation by the first convolution (and by
+# its weight gradient) instead of being gathered into a second buffer by a launch of its own (0 = gather first)
+GATHER_IN_CONV = int(os.environ.get("PPO_AMD_GATHER_IN_CONV", "1"))
 HEAD_NAMES = ("policy_head", "value_head", "advantage_head", "tvf_head")
 
 
@@ -369,6 +372,7 @@ class DualHeadNet:
         self.act_tail = None
         self._chain_split_usable = None  # decided at the first split launch (see _encode_impala)
         self.allow_chain_split = False   # set by a caller that checks chain_split_error() afterwards
+        self.obs_index = None  # [B] int32 (device): the next TRAINING forward reads observation i at x[obs_index[i]] (see takes_obs_index)
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
@@ -837,8 +841,9 @@ class DualHeadNet:
 
     def _encode_impala(self, x, train, tag):
         sp = self.spec
-        B = x.shape[0]
-        acts = {"x": x}
+        index = self.obs_index if train else None
+        B = x.shape[0] if index is None else int(index.shape[0])
+        acts = {"x": x, "in0_index": index}
         cur, cur_mode = x, (IN_U8 if x.dtype == torch.uint8 else IN_NONE)
         pending = None  # (pooled map, pointer arrays, output buffers) of a stack whose blocks the next launch runs
         for si, (cin, cout, h, w, ho, wo) in enumerate(sp.stacks):
@@ -899,9 +904,14 @@ class DualHeadNet:
             if FUSE_POOL_STACKS >> si & 1:
                 # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
                 pk = self._pk.get((wname, 0))
-                self._call("ppo_conv3x3_pool_forward_f32" if pk is None else "ppo_conv3x3_pool_forward_packed_f32",
-                           _p(cur), cur_mode, _p(self.params[wname + ".weight"] if pk is None else pk),
-                           _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
+                if si == 0 and index is not None:
+                    # the minibatch's rows of the whole batch, through the permutation: no gather launch, no second copy
+                    self._call("ppo_conv3x3_pool_forward_packed_indexed_f32", _p(cur), _p(index), cur_mode, _p(pk),
+                               _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
+                else:
+                    self._call("ppo_conv3x3_pool_forward_f32" if pk is None else "ppo_conv3x3_pool_forward_packed_f32",
+                               _p(cur), cur_mode, _p(self.params[wname + ".weight"] if pk is None else pk),
+                               _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
             else:
                 c = self._buf(f"{tag}c{si}", (B, cout, h, w))
                 self._conv(cur, cur_mode, wname, c, None, B, cin, cout, h, w)
@@ -1131,7 +1141,10 @@ class DualHeadNet:
             if WGRAD_BATCH_REDUCE:
                 ws = self._ws("wgrad_ws_" + wname, nbytes)  # per layer: the slabs live until the batched reduction
                 n_slabs = ctypes.c_int(0)
-                if argmax is not None:
+                if argmax is not None and acts.get("in0_index") is not None and wname == "encoder.stacks.0.firstconv":
+                    args_ = ("ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32", _p(x), _p(acts["in0_index"]), mode, _p(dy),
+                             _p(argmax), _p(ws), nbytes, n, cin, cout, hh, ww, ctypes.addressof(n_slabs))
+                elif argmax is not None:
                     args_ = ("ppo_conv3x3_backward_weight_slabs_pooled_f32", _p(x), mode, _p(dy), _p(argmax), _p(ws),
                              nbytes, n, cin, cout, hh, ww, ctypes.addressof(n_slabs))
                 else:
@@ -1316,8 +1329,26 @@ class DualHeadNet:
         return self._wgrad_stream
 
     # ------------------------------------------------------------------ minibatch losses + optimiser
-    def _train_forward(self, prev_state):
-        acts = self.encode(prev_state, train=True)
+    def takes_obs_index(self, obs) -> bool:
+        """Whether a training minibatch can read its observations out of the whole batch through the permutation
+        (ppo_conv3x3_pool_forward_packed_indexed_f32 + the indexed first-layer weight gradient) instead of from a
+        gathered copy: uint8 images into the fused first convolution + max-pool, the pooled-gradient weight-gradient form."""
+        if self.encoder_kind != "impala" or obs.dtype != torch.uint8 or self.obs_norm is not None or not GATHER_IN_CONV:
+            return False
+        cin, cout, h, w, _ho, _wo = self.spec.stacks[0]
+        return bool(FUSE_POOL_STACKS & 1) and self._pk.get(("encoder.stacks.0.firstconv", 0)) is not None \
+            and bool(WGRAD_POOLED_DY and WGRAD_BATCH_REDUCE) \
+            and bool(self.lib.ppo_conv3x3_backward_weight_pooled_supported(cin, cout, h, w))
+
+    def _train_forward(self, prev_state, index=None):
+        if index is not None and prev_state.shape[0] != index.shape[0]:
+            if not self.takes_obs_index(prev_state):
+                raise ValueError("this net needs the gathered minibatch of observations (takes_obs_index is False)")
+            self.obs_index = index
+        try:
+            acts = self.encode(prev_state, train=True)
+        finally:
+            self.obs_index = None
         o = self.heads(acts, "t")
         B = o.shape[0]
         return acts, o, B, self._buf("dheads", (B, self.nh))
@@ -1340,7 +1371,7 @@ class DualHeadNet:
                 grad_scale=float(loss_scale) / B, n_actions=self.n_actions, n_value_heads=self.vh if returns is not None else 0,
                 returns=_p(returns), vf_coef=float(vf_coef), actions_i=_p(actions), old_log_pac=_p(old_log_pac),
                 old_log_policy=_p(old_log_policy), advantages=_p(advantages), eps_clip=float(eps_clip), ent_coef=float(ent_coef))
-        acts, o, B, dheads = self._train_forward(prev_state)
+        acts, o, B, dheads = self._train_forward(prev_state, index)
         stats = self._buf("loss_stats", (B, 8))
         vh = self.vh if returns is not None else 0
         self._call("ppo_ppo_loss_f32", _p(o), B, self.nh, self.n_actions, vh, _p(actions), _p(old_log_pac),
@@ -1360,7 +1391,7 @@ class DualHeadNet:
                 returns=_p(returns), vf_coef=float(vf_coef), actions_f=_p(actions), old_log_pac=_p(old_log_pac),
                 advantages=_p(advantages), log_std=_p(self.params["log_std"]), eps_clip=float(eps_clip),
                 dlog_std_rows=_p(self._buf("dlog_std_rows", (B, self.n_actions))))
-        acts, o, B, dheads = self._train_forward(prev_state)
+        acts, o, B, dheads = self._train_forward(prev_state, index)
         stats = self._buf("loss_stats", (B, 8))
         rows = self._buf("dlog_std_rows", (B, self.n_actions))
         vh = self.vh if returns is not None else 0
@@ -1386,7 +1417,7 @@ class DualHeadNet:
                 n_tvf=self.K if tvf_returns is not None else 0, tvf_stride=max(self.vh, 1), tvf_returns=_p(tvf_returns),
                 tvf_weights=_p(tvf_weights), tvf_coef=float(tvf_coef), tvf_keep_prob=float(tvf_keep_prob),
                 seed=int(dropout_seed) & (2**64 - 1), offset=int(dropout_offset) & (2**64 - 1))
-        acts, o, B, dheads = self._train_forward(prev_state)
+        acts, o, B, dheads = self._train_forward(prev_state, index)
         stats = self._buf("value_stats", (B, 4))
         self._call("ppo_value_loss_f32", _p(o), B, self.nh, self.col_value, self.vh if returns is not None else 0,
                    _p(returns), float(vf_coef), self.col_tvf if self.K else 0, self.K if tvf_returns is not None else 0,
@@ -1408,7 +1439,7 @@ class DualHeadNet:
                 grad_scale=float(loss_scale) / B, n_actions=self.n_actions, pred_col=col, n_pred=n_pred, pred_stride=stride,
                 vector_targets=1 if use_tvf else 0, targets=_p(targets), weights=_p(weights), old_policy=_p(old_policy),
                 log_std=_p(self.params["log_std"]) if gaussian else None, beta=float(beta))
-        acts, o, B, dheads = self._train_forward(prev_state)
+        acts, o, B, dheads = self._train_forward(prev_state, index)
         stats = self._buf("distil_stats", (B, 4))
         self._call("ppo_distil_loss_f32", _p(o), B, self.nh, self.n_actions, col, n_pred, stride, 1 if use_tvf else 0,
                    _p(targets), _p(weights), _p(old_policy), _p(self.params["log_std"]) if gaussian else None,

@@ -822,7 +822,10 @@ class Runner:
         # MLP nets on the fused path read their rows of the whole batch through the permutation and column-sum the
         # statistics in their weight-gradient launch: no gather launch, no column-sum launch
         fused = bool(getattr(net, "mlp_fused", False)) and net.obs_norm is None and self.all_obs.dtype == torch.float32
-        mb_obs = None if fused else net._buf("mb_obs", (micro, *self.state_shape), self.all_obs.dtype)
+        # ... and the IMPALA nets read uint8 image rows through the permutation in their first convolution
+        in_conv = not fused and hasattr(net, "takes_obs_index") and net.takes_obs_index(self.all_obs)
+        obs_all = self.all_obs[:self.N].view(B, *self.state_shape)
+        mb_obs = None if (fused or in_conv) else net._buf("mb_obs", (micro, *self.state_shape), self.all_obs.dtype)
         stat_rows = net._buf(f"stat_rows_{label}", (epochs * n_mb, n_stats))
         norm_rows = net._buf(f"norm_rows_{label}", (epochs * n_mb,))
         k = 0
@@ -839,8 +842,11 @@ class Runner:
                             step_fn(obs_rows, idx, 1.0 / n_micro, stat_sums=stat_rows[k], stat_accumulate=bool(u))
                             acc.after_backward()
                             continue
-                        self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), micro, _p(mb_obs))
-                        stats = step_fn(mb_obs, idx, 1.0 / n_micro)
+                        if in_conv:
+                            stats = step_fn(obs_all, idx, 1.0 / n_micro)
+                        else:
+                            self._call("ppo_gather_rows", _p(obs_rows), row_bytes, B, _p(idx), micro, _p(mb_obs))
+                            stats = step_fn(mb_obs, idx, 1.0 / n_micro)
                         acc.after_backward()
                         self._call("ppo_colsum_f32", _p(stats), micro, n_stats, n_stats, _p(stat_rows[k]), 1 if u else 0)
                     acc.finish()

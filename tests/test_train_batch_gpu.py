@@ -132,3 +132,35 @@ def test_max_micro_batch_size_flag_splits_the_fast_path():
     a, b = one.fetch_stats(), two.fetch_stats()
     for k in ("loss_policy", "entropy", "kl_approx", "clip_frac"):
         assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), k
+
+
+def test_minibatch_read_through_the_permutation_equals_the_gathered_minibatch():
+    """uint8 image minibatches are read out of the whole batch by the first convolution and by its weight gradient
+    (ppo_conv3x3_pool_forward_packed_indexed_f32 / ..._slabs_pooled_indexed_f32) instead of from a gathered copy: same
+    statistics, same gradient, bit for bit."""
+    from ppo_amd import models
+    torch.manual_seed(5)
+    net = models.DualHeadNet("impala", (4, 84, 84), 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Btot, B = 96, 32
+    obs = torch.randint(0, 256, (Btot, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    idx = torch.randperm(Btot, device="cuda", generator=g)[:B].int().contiguous()
+    actions = torch.randint(0, 6, (Btot,), dtype=torch.int32, device="cuda", generator=g)
+    adv = torch.randn(Btot, device="cuda", generator=g)
+    ret = torch.randn(Btot, 1, device="cuda", generator=g)
+    lp = torch.log_softmax(torch.randn(Btot, 6, device="cuda", generator=g), dim=1)
+    pac = lp.gather(1, actions.long()[:, None])[:, 0].contiguous()
+    assert net.takes_obs_index(obs)
+    gathered = obs[idx.long()].contiguous()
+    net.grad.zero_()
+    s_g = net.ppo_minibatch(gathered, actions, pac, lp, adv, ret, index=idx).clone()
+    g_g = net.grad.clone()
+    calls = []
+    orig = net._call
+    net._call = lambda fn, *a: (calls.append(fn), orig(fn, *a))[1]
+    net.grad.zero_()
+    s_i = net.ppo_minibatch(obs, actions, pac, lp, adv, ret, index=idx).clone()
+    torch.cuda.synchronize()
+    assert "ppo_conv3x3_pool_forward_packed_indexed_f32" in calls and "ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32" in calls
+    assert torch.equal(s_g, s_i) and torch.equal(g_g, net.grad) and float(g_g.abs().max()) > 0
+    assert net.obs_index is None
