@@ -388,7 +388,7 @@ def _describe_call(fn, a):
     if fn == "ppo_conv3x3_backward_weight_slabs_pooled_f32":
         n, ci, co, h, w = a[6:11]
         return f"conv3x3 wgrad+pool-bwd {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
-    if fn == "ppo_conv3x3_backward_weight_slabs_batch_f32":
+    if fn in ("ppo_conv3x3_backward_weight_slabs_batch_f32", "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32"):
         k, n, ci, co, h, w = a[5:11]
         return f"conv3x3 wgrad x{k} {ci}->{co} {h}x{w}", k * _conv(n, ci, co, h, w), None
     if fn == "ppo_conv3x3_backward_weight_f32":

@@ -207,6 +207,14 @@ int ppo_conv3x3_backward_weight_slabs_f32(const void *in, int in_mode, const flo
 int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *ins, int in_mode, const float *const *dys,
                                                 void *const *workspaces, size_t workspace_bytes, int count, int n, int cin,
                                                 int cout, int h, int w, int *n_slabs, void *stream);
+/* The same launch with a per-problem load transform: relu[k] != 0 reads problem k's input through the forward's ReLU
+ * (block convolutions), 0 reads it raw (a stack-first convolution): the first convolution of the NEXT stack has the
+ * geometry of this stack's block convolutions and its gradient is known by the time theirs are, so it rides in their
+ * launch as a fifth problem instead of paying a launch of its own (11 - 14 us fixed, profiles/r04_wgrad_fixed_cost.md).
+ * Same slabs, same bits as the separate launches of the same grid. */
+int ppo_conv3x3_backward_weight_slabs_batch_mixed_f32(const void *const *ins, const int *relu, const float *const *dys,
+                                                      void *const *workspaces, size_t workspace_bytes, int count, int n,
+                                                      int cin, int cout, int h, int w, int *n_slabs, void *stream);
 /* A stack's FIRST convolution with its dy taken from the pooled gradient: dy = ppo_maxpool3x3s2_backward_f32(g, argmax)
  * is formed band by band inside the kernel (g [n,cout,h/2,w/2], argmax uint8 likewise), so the pre-pool gradient map
  * never exists in HBM.  Same slabs as the max-pool backward launch followed by ppo_conv3x3_backward_weight_slabs_f32.

@@ -135,7 +135,7 @@ template <class C, int NTW, bool RELU, int KGI>
 __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, const float *__restrict__ s_d,
                                              const int (&joff)[C::NTW_MAX], const int (&ml)[C::NTW_MAX],
                                              const int (&mr)[C::NTW_MAX], int aoff, int g,
-                                             f32x4 (&acc)[C::MTC][C::NTW_MAX], float (&asum)[C::MTC])
+                                             f32x4 (&acc)[C::MTC][C::NTW_MAX], float (&asum)[C::MTC], float floor)
 {
     constexpr int SPR = C::RUN ? 1 : C::PWD / 4;  // steps per row (halo-column layout)
     constexpr int S0 = KGI * C::STEPS / C::KG, S1 = (KGI + 1) * C::STEPS / C::KG;
@@ -162,7 +162,9 @@ __device__ __forceinline__ void wgrad_k_loop(const float *__restrict__ s_x, cons
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             float bv = b[i % (PF + 1)][t];
-            if (RELU) bv = relu1(bv);  // the band was staged raw by LDS-DMA: the forward's ReLU-on-load is applied here
+            // the band was staged raw by LDS-DMA: the forward's ReLU-on-load is applied here (floor 0: relu1's own v_med3;
+            // floor -inf: the identity, for a problem of the batch whose forward read its input raw)
+            if (RELU) bv = __builtin_amdgcn_fmed3f(bv, floor, __builtin_inff());
             if constexpr (C::RUN) {
                 // pixel 4s + e sits in column (4s + e) % W: in the first column the x-1 taps, in the last the x+1 taps
                 // read a neighbouring row's pixel.  ml / mr hold the lane's pixel phase g when its column's tap is an
@@ -191,14 +193,14 @@ template <class C, bool RELU, int KGI = 0>
 __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, const float *__restrict__ s_d,
                                               const int (&joff)[C::NTW_MAX], const int (&ml)[C::NTW_MAX],
                                               const int (&mr)[C::NTW_MAX], int aoff, int g, int wt, int kg,
-                                              f32x4 (&acc)[C::MTC][C::NTW_MAX], float (&asum)[C::MTC])
+                                              f32x4 (&acc)[C::MTC][C::NTW_MAX], float (&asum)[C::MTC], float floor)
 {
     constexpr int NLO = C::NTW_MAX > 1 ? C::NTW_MAX - 1 : 1;
     if (kg == KGI) {
-        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU, KGI>(s_x, s_d, joff, ml, mr, aoff, g, acc, asum);
-        else if (C::NTW_MAX > 1) wgrad_k_loop<C, NLO, RELU, KGI>(s_x, s_d, joff, ml, mr, aoff, g, acc, asum);
+        if (wt < C::REM) wgrad_k_loop<C, C::NTW_MAX, RELU, KGI>(s_x, s_d, joff, ml, mr, aoff, g, acc, asum, floor);
+        else if (C::NTW_MAX > 1) wgrad_k_loop<C, NLO, RELU, KGI>(s_x, s_d, joff, ml, mr, aoff, g, acc, asum, floor);
     } else if constexpr (KGI + 1 < C::KG) {
-        wgrad_k_loops<C, RELU, KGI + 1>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum);
+        wgrad_k_loops<C, RELU, KGI + 1>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum, floor);
     }
 }
 
@@ -207,11 +209,13 @@ __device__ __forceinline__ void wgrad_k_loops(const float *__restrict__ s_x, con
 // workgroups has one ramp and one tail where four launches have four (per-launch constant ~10 us).
 // set by ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32 around its dispatch (see WgradBatch::in_index)
 thread_local const int32_t *t_wgrad_in_index = nullptr;
-constexpr int kWgradBatch = 4;
+constexpr int kWgradBatch = 5;  // a stack's four block convolutions + the next stack's first convolution (same geometry)
 struct WgradBatch {
     const void *in[kWgradBatch];
     const float *dy[kWgradBatch];  // DY_POOLED: the POOLED gradient g [n, COUT, H/2, W/2] ...
     float *partial[kWgradBatch];
+    float relu_floor[kWgradBatch]; // IN_RELU launches: the lower clamp of the input on load, per problem - 0 = the forward's
+                                   // ReLU, -inf = the raw input (a first convolution riding in a block batch)
     const uint8_t *argmax;         // ... and the pooling's argmax (problem 0 only): dy = maxpool_backward(g, argmax)
     const int32_t *in_index;       // nullable (uint8 input only): image i of the launch is image in_index[i] of `in` - the
                                    // minibatch permutation, so that the observations need no gathered copy
@@ -226,6 +230,7 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
     const void *__restrict__ in_ = batch.in[blockIdx.y];
     const float *__restrict__ dy = batch.dy[blockIdx.y];
     float *__restrict__ partial = batch.partial[blockIdx.y];
+    const float relu_floor = batch.relu_floor[blockIdx.y];
     extern __shared__ __align__(16) float smem[];
     float *s_x = smem;
     float *s_d = smem + C::LDS_X;
@@ -328,7 +333,7 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
             if (item + (int)gridDim.x < n_items && (!DMAW || is_dma))
                 stage(item + gridDim.x, s_x + (buf ^ 1) * C::LDS_BUF, s_d + (buf ^ 1) * C::LDS_BUF);
             PPO_STAMP(t_staged)
-            if (!is_dma) wgrad_k_loops<C, RELU>(bx, bd, joff, ml, mr, aoff, g, wt, kg, acc, asum);
+            if (!is_dma) wgrad_k_loops<C, RELU>(bx, bd, joff, ml, mr, aoff, g, wt, kg, acc, asum, relu_floor);
             PPO_STAMP(t_end)
             PPO_STAMP_ADD(0, t_bar, t_top)      // barrier wait
             PPO_STAMP_ADD(1, t_staged, t_bar)   // DMA issue of the next item
@@ -370,7 +375,7 @@ __global__ __launch_bounds__((wgrad_threads<IN_MODE, (H + TR - 1) / TR, DY_POOLE
                 __syncthreads();
             }
             PPO_STAMP(t_staged)
-            wgrad_k_loops<C, RELU>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum);
+            wgrad_k_loops<C, RELU>(s_x, s_d, joff, ml, mr, aoff, g, wt, kg, acc, asum, relu_floor);
             PPO_STAMP(t_end)
             PPO_STAMP_ADD(0, t_bar, t_top)      // barrier wait
             PPO_STAMP_ADD(1, t_staged, t_bar)   // staging (single-buffered: exposed)
@@ -608,7 +613,8 @@ int launch_wgrad(const void *in, const float *dy, float *dw, float *db, float *w
     // is ONE wave of workgroups, each walking count x as many items — a quarter of the slabs to write and reduce
     // (4 x 256 slabs of 39 KB were 1.6-2.3 x the tensors themselves for the 21x21 / 11x11 layers) and a quarter of the
     // per-workgroup prologue / K-group fold
-    int grid = (256 * per_cu + count - 1) / count;
+    int grid = (256 * per_cu) / count;  // rounded DOWN: 5 x 52 workgroups would need a second wave for the last four
+    if (grid < 1) grid = 1;
     if (grid > kWgradMaxSlabs) grid = kWgradMaxSlabs;
     if (grid > n_items) grid = n_items;
     const size_t need = (size_t)grid * COUT * C::JP * sizeof(float);
@@ -755,6 +761,29 @@ extern "C" int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *in
         case IN_U8: return dispatch_wgrad<IN_U8>(cin, cout, h, w, b.in[0], b.dy[0], nullptr, nullptr, ws, workspace_bytes, n, 0, st, n_slabs, &b, count);
     }
     return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_f32: unknown in_mode %d", in_mode);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_slabs_batch_mixed_f32(const void *const *ins, const int *relu, const float *const *dys,
+                                                                 void *const *workspaces, size_t workspace_bytes, int count,
+                                                                 int n, int cin, int cout, int h, int w, int *n_slabs,
+                                                                 void *stream)
+{
+    using namespace ppo;
+    if (n <= 0 || count < 1 || count > kWgradBatch)
+        return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32: n must be positive, count in 1..%d", kWgradBatch);
+    if (!ins || !relu || !dys || !workspaces || !n_slabs)
+        return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32: null pointer");
+    WgradBatch b{};
+    for (int k = 0; k < count; ++k) {
+        if (!ins[k] || !dys[k] || !workspaces[k])
+            return fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32: null pointer in problem %d", k);
+        b.in[k] = ins[k];
+        b.dy[k] = dys[k];
+        b.partial[k] = static_cast<float *>(workspaces[k]);
+        b.relu_floor[k] = relu[k] ? 0.f : -__builtin_inff();
+    }
+    return dispatch_wgrad<IN_RELU>(cin, cout, h, w, b.in[0], b.dy[0], nullptr, nullptr, b.partial[0], workspace_bytes, n, 0,
+                                   as_stream(stream), n_slabs, &b, count);
 }
 
 extern "C" int ppo_conv3x3_backward_weight_slabs_pooled_f32(const void *in, int in_mode, const float *g,

@@ -41,6 +41,10 @@ WGRAD_BATCH_LAUNCH = int(os.environ.get("PPO_AMD_WGRAD_BATCH_LAUNCH", "1"))
 # max-pool backward launch (37 us) goes, the weight-gradient kernel grows by ~20 us (it gathers (argmax, g) pairs
 # instead of streaming the map in by LDS-DMA): -15 us per step net and a 115 MB tensor less.
 WGRAD_POOLED_DY = int(os.environ.get("PPO_AMD_WGRAD_POOLED_DY", "1"))
+# a stack's first convolution whose geometry equals the PREVIOUS stack's block convolutions (32 -> 32 at 21x21 for the 84x84
+# net) has its weight gradient formed by that stack's batched launch, as a fifth problem read without the ReLU
+# (ppo_conv3x3_backward_weight_slabs_batch_mixed_f32): one launch less per backward pass (11 - 14 us of fixed cost)
+WGRAD_RIDE = int(os.environ.get("PPO_AMD_WGRAD_RIDE", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -1167,20 +1171,39 @@ class DualHeadNet:
                 jobs.append(_lib.WgradJob(_p(ws), _p(self.grads[wname + ".weight"]), _p(self.grads[wname + ".bias"]),
                                           n_slabs.value, cin, cout, 0))
 
+        carry = []  # [(x, dy, wname, n, c, hh, ww)]: a first convolution waiting for the next batched launch of its geometry
+
+        def flush_carry():
+            while carry:
+                x, dy, wname, n, c, hh, ww = carry.pop()
+                wgrad(x, IN_NONE, dy, wname, n, c, c, hh, ww)
+
         def wgrad_blocks(problems, n, c, hh, ww):
             """Weight gradients of a stack's block convolutions, problems = [(x, dy, wname)] (all IN_RELU, c -> c)."""
             if not (WGRAD_BATCH_LAUNCH and WGRAD_BATCH_REDUCE) or len(problems) > 4:
+                flush_carry()
                 for x, dy, wname in problems:
                     wgrad(x, IN_RELU, dy, wname, n, c, c, hh, ww)
                 return
+            relu = [1] * len(problems)
+            if carry and carry[-1][3:] == (n, c, hh, ww):
+                x, dy, wname = carry.pop()[:3]
+                problems = list(problems) + [(x, dy, wname)]
+                relu.append(0)  # the stack-first convolution read its input raw
+            flush_carry()
             nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(c, c)
             wss = [self._ws("wgrad_ws_" + wname, nbytes) for _x, _dy, wname in problems]
             k = len(problems)
             n_slabs = ctypes.c_int(0)
-            args_ = ("ppo_conv3x3_backward_weight_slabs_batch_f32", (ctypes.c_void_p * k)(*[x.data_ptr() for x, _d, _w in problems]),
-                     IN_RELU, (ctypes.c_void_p * k)(*[dy.data_ptr() for _x, dy, _w in problems]),
-                     (ctypes.c_void_p * k)(*[ws.data_ptr() for ws in wss]), nbytes, k, n, c, c, hh, ww,
-                     ctypes.addressof(n_slabs))
+            ins = (ctypes.c_void_p * k)(*[x.data_ptr() for x, _d, _w in problems])
+            dys = (ctypes.c_void_p * k)(*[dy.data_ptr() for _x, dy, _w in problems])
+            wsp = (ctypes.c_void_p * k)(*[ws.data_ptr() for ws in wss])
+            if k > 4:
+                args_ = ("ppo_conv3x3_backward_weight_slabs_batch_mixed_f32", ins, (ctypes.c_int * k)(*relu), dys, wsp, nbytes, k, n,
+                         c, c, hh, ww, ctypes.addressof(n_slabs))
+            else:
+                args_ = ("ppo_conv3x3_backward_weight_slabs_batch_f32", ins, IN_RELU, dys, wsp, nbytes, k, n, c, c, hh, ww,
+                         ctypes.addressof(n_slabs))
             if side is None:
                 self._call(*args_)
             else:
@@ -1266,12 +1289,18 @@ class DualHeadNet:
                 continue
             dc = self._buf(f"g{si}_dc", (B, cout, hh, ww))
             self._call("ppo_maxpool3x3s2_backward_f32", _p(g), _p(acts[f"idx{si}"]), _p(dc), B, cout, hh, ww)
-            wgrad(x_in, mode, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
+            if WGRAD_RIDE and WGRAD_BATCH_LAUNCH and WGRAD_BATCH_REDUCE and side is None and si > 0 and cin == cout \
+                    and mode == IN_NONE and sp.n_block == 2 and sp.stacks[si - 1][1] == cin \
+                    and tuple(sp.stacks[si - 1][4:6]) == (hh, ww):
+                carry.append((x_in, dc, f"encoder.stacks.{si}.firstconv", B, cin, hh, ww))  # rides in the next stack's launch
+            else:
+                wgrad(x_in, mode, dc, f"encoder.stacks.{si}.firstconv", B, cin, cout, hh, ww)
             if si > 0:
                 g = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
                 fc = f"encoder.stacks.{si}.firstconv"
                 self._call(self._bwd_data_fn(fc), _p(dc), _p(self._bwd_w(fc)),
                            None, None, _p(g), B, cin, cout, hh, ww)
+        flush_carry()
         if jobs:
             table = (_lib.WgradJob * len(jobs))(*jobs)
             if side is None:

@@ -383,7 +383,8 @@ def test_fused_stack_tail_is_bit_identical_to_four_convolutions(monkeypatch, dim
         assert float(a.grad.abs().sum()) > 0, B
         for name in a.grads:
             ga, gb = a.grads[name], b.grads[name]
-            if ".blocks." in name:
+            if ".blocks." in name or name.startswith("encoder.stacks.2.firstconv"):
+                # (the last stack's first convolution rides in the 21x21 blocks' launch as its fifth problem: WGRAD_RIDE)
                 assert float((ga - gb).abs().max()) <= 2e-6 * max(float(gb.abs().max()), 1e-30), (B, name)
             else:
                 assert torch.equal(ga, gb), (B, name)
