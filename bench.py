@@ -364,7 +364,7 @@ def _batch_of(fn, a):
         return a[8]
     if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3"):
         return a[7]
-    if fn in ("ppo_dense_heads_forward_f32", "ppo_dense_heads_act_forward_f32"):
+    if fn in ("ppo_dense_heads_forward_f32", "ppo_dense_heads_act_forward_f32", "ppo_dense_heads_loss_forward_f32"):
         return a[9]
     if fn == "ppo_conv3x3_block_forward_packed_f32":
         return a[6]
@@ -430,6 +430,9 @@ def _describe_call(fn, a):
     if fn == "ppo_dense_heads_forward_f32":  # (x, relu_x, W, b, Wh, bh, relu_h, h, heads, M, K, H, NH, ws, ws_bytes)
         M, K, H, NH = a[9:13]
         return f"dense + heads fwd {M}x{K}x{H} (+{NH})", 2.0 * M * H * (K + NH), None
+    if fn == "ppo_dense_heads_loss_forward_f32":  # the same + the PPO loss's arguments
+        M, K, H, NH = a[9:13]
+        return f"dense + heads + PPO loss fwd {M}x{K}x{H} (+{NH})", 2.0 * M * H * (K + NH), None
     if fn == "ppo_dense_heads_act_forward_f32":  # the same + (n_actions, temperature, seed, offset, outputs...)
         M, K, H, NH = a[9:13]
         return f"dense + heads + action sampling fwd {M}x{K}x{H} (+{NH})", 2.0 * M * H * (K + NH), None

@@ -275,6 +275,16 @@ int ppo_dense_heads_act_forward_f32(const float *x, int relu_x, const float *W, 
                                     void *workspace, size_t workspace_bytes, int n_actions, float temperature,
                                     uint64_t seed, uint64_t offset, float *log_policy, int32_t *actions, float *log_pac,
                                     float *raw_policy, float *values, int n_value_heads, void *stream);
+/* The TRAINING counterpart: dense layer + heads + the discrete PPO loss of Runner.train_policy_minibatch
+ * (rl/rollout.py:1640-1660, 1682, 1744-1753, 1596-1608; arguments as ppo_ppo_loss_f32) on the finished head row in the
+ * finalize launch: dheads and the statistics rows leave from there.  Bit-identical to ppo_dense_heads_forward_f32 followed by
+ * ppo_ppo_loss_f32; shapes without a fused form run exactly those launches inside the entry point. */
+int ppo_dense_heads_loss_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh, const float *bh,
+                                     int relu_h, float *h, float *heads, int M, int K, int H, int NH, void *workspace,
+                                     size_t workspace_bytes, int n_actions, int n_value_heads, const int32_t *actions,
+                                     const float *old_log_pac, const float *old_log_policy, const float *advantages,
+                                     const float *returns, float eps_clip, float ent_coef, float vf_coef, float grad_scale,
+                                     float *dheads, float *stats, const int32_t *index, void *stream);
 
 /*
  * Backward of the fused heads in one launch: dh[B,H] = (dheads[B,NH] @ Wh[NH,H]) * [gate > 0] (gate [B,H] nullable: the

@@ -47,6 +47,8 @@ SIGNATURES = {
     "ppo_dense_heads_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ppo_dense_heads_act_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _f, _u64,
                                              _u64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ppo_dense_heads_loss_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp, _vp, _vp,
+                                              _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ppo_policy_act_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ppo_gather_rows": (_i, [_vp, _i64, _i64, _vp, _i, _vp, _vp]),
     "ppo_moments_workspace_bytes": (_sz, []),

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "loss_rows.h"
 #include "policy_act.h"
 #include "mfma.h"
 
@@ -547,6 +548,12 @@ struct ActTail {
     float temperature;
     uint64_t seed, offset;
     ActOut out;
+    // ... or, in a TRAINING forward (loss != 0), the discrete PPO loss on the finished head row (loss_rows.h: the body of
+    // ppo_loss_kernel, same bits): d loss / d heads and the statistics row leave from here and the loss launch is gone
+    int loss;
+    PpoLossP lp;
+    float *dheads;
+    const int32_t *index;
 };
 
 // NHT: head columns handled (16 or 32: the 15-action suites have 2 * 15 + 1 = 31 heads; their head weights take 128 registers)
@@ -611,6 +618,11 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
         heads[m * NH + lane] = out;
     }
     if constexpr (NA > 0) {
+        if (act.loss) {
+            ppo_loss_row_z<NA>(act.lp, [&](int i) { return __shfl(out, i, 64); }, act.dheads + (size_t)m * NH, m,
+                               act.index ? act.index[m] : m, lane == 0);
+            return;
+        }
         // raw logits and recorded values: each lane stores its own column (a lane-0 store loop would read the other
         // lanes from inside a divergent branch); the per-sample body then only broadcasts logits in uniform control flow
         if (act.out.raw_policy && lane < NA) act.out.raw_policy[(size_t)m * NA + lane] = out;
@@ -899,7 +911,8 @@ extern "C" int ppo_dense_heads_act_forward_f32(const float *x, int relu_x, const
     if (!(temperature > 0.f)) return fail(PPO_E_INVALID, "ppo_dense_heads_act_forward_f32: temperature must be > 0");
     if (M == 0) return PPO_OK;
     if (!x || !W || !Wh || !h || !heads) return fail(PPO_E_INVALID, "ppo_dense_heads_act_forward_f32: null pointer");
-    const ActTail act{temperature, seed, offset, ActOut{log_policy, actions, log_pac, raw_policy, values, n_value_heads}};
+    const ActTail act{temperature, seed, offset, ActOut{log_policy, actions, log_pac, raw_policy, values, n_value_heads}, 0,
+                      PpoLossP{}, nullptr, nullptr};
     HeadsTail tail{Wh, bh, heads, NH, relu_h, false};
     tail.act = &act;
     tail.act_n = n_actions;
@@ -910,6 +923,44 @@ extern "C" int ppo_dense_heads_act_forward_f32(const float *x, int relu_x, const
     if (rc || tail.act_fused) return rc;
     return ppo_policy_act_f32(heads, M, NH, n_actions, temperature, nullptr, seed, offset, 0, log_policy, actions, log_pac,
                               raw_policy, values, n_value_heads, stream);
+}
+
+extern "C" int ppo_ppo_loss_f32(const float *heads, int B, int ldo, int n_actions, int n_value_heads, const int32_t *actions,
+                                const float *old_log_pac, const float *old_log_policy, const float *advantages,
+                                const float *returns, float eps_clip, float ent_coef, float vf_coef, float grad_scale,
+                                float *dheads, float *stats, const int32_t *index, void *stream);
+
+extern "C" int ppo_dense_heads_loss_forward_f32(const float *x, int relu_x, const float *W, const float *b, const float *Wh,
+                                                const float *bh, int relu_h, float *h, float *heads, int M, int K, int H,
+                                                int NH, void *workspace, size_t workspace_bytes, int n_actions,
+                                                int n_value_heads, const int32_t *actions, const float *old_log_pac,
+                                                const float *old_log_policy, const float *advantages, const float *returns,
+                                                float eps_clip, float ent_coef, float vf_coef, float grad_scale, float *dheads,
+                                                float *stats, const int32_t *index, void *stream)
+{
+    using namespace ppo;
+    if (M < 0 || K < 0 || H <= 0 || NH <= 0) return fail(PPO_E_INVALID, "ppo_dense_heads_loss_forward_f32: bad dimension");
+    if (n_actions <= 0 || n_actions > kMaxActions || n_value_heads < 0 || NH < n_actions + n_value_heads)
+        return fail(PPO_E_INVALID, "ppo_dense_heads_loss_forward_f32: bad head layout (n_actions=%d value heads=%d of %d)",
+                    n_actions, n_value_heads, NH);
+    if (M == 0) return PPO_OK;
+    if (!x || !W || !Wh || !h || !heads || !actions || !old_log_pac || !advantages || !dheads || (n_value_heads > 0 && !returns))
+        return fail(PPO_E_INVALID, "ppo_dense_heads_loss_forward_f32: null pointer");
+    ActTail act{};
+    act.loss = 1;
+    act.lp = PpoLossP{NH, n_actions, n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns, eps_clip,
+                      ent_coef, vf_coef, grad_scale, stats};
+    act.dheads = dheads, act.index = index;
+    HeadsTail tail{Wh, bh, heads, NH, relu_h, false};
+    tail.act = &act;
+    tail.act_n = n_actions;
+    int rc = gemm_dispatch(x, K, 1, relu_x, W, 1, K, 0, b, nullptr, h, H, M, H, K, workspace, workspace_bytes, stream, &tail);
+    if (rc) return rc;
+    if (!tail.fused)
+        rc = gemm_dispatch(h, H, 1, relu_h, Wh, 1, H, 0, bh, nullptr, heads, NH, M, NH, H, nullptr, 0, stream, nullptr);
+    if (rc || tail.act_fused) return rc;
+    return ppo_ppo_loss_f32(heads, M, NH, n_actions, n_value_heads, actions, old_log_pac, old_log_policy, advantages, returns,
+                            eps_clip, ent_coef, vf_coef, grad_scale, dheads, stats, index, stream);
 }
 
 extern "C" int ppo_heads_backward_f32(const float *dheads, const float *hin, int relu_in, const float *gate, const float *Wh,

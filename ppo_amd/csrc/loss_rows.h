@@ -222,9 +222,11 @@ struct PpoLossP {
     float eps_clip, ent_coef, vf_coef, grad_scale;
     float *stats;
 };
-// one THREAD per sample.  NA: the action count at compile time (0 = any)
-template <int NA>
-__device__ __forceinline__ void ppo_loss_row(const PpoLossP &q, const float *z, float *dz, int b, int sb)
+// one THREAD per sample (`store` true), or - in the dense + heads + loss launch, where the head row sits in a wave's lanes
+// and z(i) is a shuffle - every lane of the wave on the same values with one lane storing.  NA: the action count at
+// compile time (0 = any).  z(i): head output i of the sample.
+template <int NA, class Z>
+__device__ __forceinline__ void ppo_loss_row_z(const PpoLossP &q, Z z, float *dz, int b, int sb, bool store)
 {
     const int nA = NA ? NA : q.nA;
     constexpr int kUnroll = NA ? 32 : 1;  // full unroll when the count is a constant
@@ -240,7 +242,7 @@ __device__ __forceinline__ void ppo_loss_row(const PpoLossP &q, const float *z, 
     float mx = -INFINITY;
 #pragma unroll kUnroll
     for (int a = 0; a < nA; ++a) {
-        lp[a] = z[a];
+        lp[a] = z(a);
         oldp[a] = old_log_policy ? old_log_policy[(size_t)sb * nA + a] : 0.f;
         mx = fmaxf(mx, lp[a]);
     }
@@ -271,11 +273,12 @@ __device__ __forceinline__ void ppo_loss_row(const PpoLossP &q, const float *z, 
     // value heads: vf_coef * (V - R)^2 per head (rl/rollout.py:1596-1608)
     float vloss = 0.f;
     for (int i = 0; i < vh; ++i) {
-        const float diff = z[nA + i] - returns[(size_t)sb * vh + i];
+        const float diff = z(nA + i) - returns[(size_t)sb * vh + i];
         vloss += vf_coef * diff * diff;
-        dz[nA + i] = grad_scale * 2.f * vf_coef * diff;  // d(-gain)/dV
+        if (store) dz[nA + i] = grad_scale * 2.f * vf_coef * diff;  // d(-gain)/dV
     }
-    for (int i = nA + vh; i < ldo; ++i) dz[i] = 0.f;
+    if (store)
+        for (int i = nA + vh; i < ldo; ++i) dz[i] = 0.f;
 
     // d(-gain)/dlogit_j = -[ dclip_dratio * ratio * (1{j=act} - p_j) + ent_coef * (-p_j (logp_j + H)) ]
     const float w = dclip_dratio * ratio;
@@ -284,9 +287,9 @@ __device__ __forceinline__ void ppo_loss_row(const PpoLossP &q, const float *z, 
         const float p = expf(lp[a]);
         const float dpg = w * ((a == act ? 1.f : 0.f) - p);
         const float dent = -p * (lp[a] + entropy);
-        dz[a] = -grad_scale * (dpg + ent_coef * dent);
+        if (store) dz[a] = -grad_scale * (dpg + ent_coef * dent);
     }
-    if (stats) {
+    if (stats && store) {
         float *s = stats + (size_t)b * ST_N;
         s[ST_LOSS_CLIP] = loss_clip;
         s[ST_ENTROPY] = entropy;
@@ -297,6 +300,12 @@ __device__ __forceinline__ void ppo_loss_row(const PpoLossP &q, const float *z, 
         s[ST_GAIN] = loss_clip + ent_coef * entropy - vloss;
         s[ST_RATIO] = ratio;
     }
+}
+
+template <int NA>
+__device__ __forceinline__ void ppo_loss_row(const PpoLossP &q, const float *z, float *dz, int b, int sb)
+{
+    ppo_loss_row_z<NA>(q, [&](int i) { return z[i]; }, dz, b, sb, true);
 }
 
 }  // namespace ppo

@@ -96,6 +96,9 @@ FUSE_BLOCK = int(os.environ.get("PPO_AMD_FUSE_BLOCK", "1"))
 # statistics; Adam) instead of ~14 launches of 8 - 20 us each.  0 = the op-by-op path (same arithmetic per element up to
 # float32 summation order; tests/test_variants_gpu.py runs both against the reference's fixtures).
 FUSE_MLP = int(os.environ.get("PPO_AMD_FUSE_MLP", "1"))
+# the discrete PPO loss runs on the finished head row inside the training forward's dense + heads launch
+# (ppo_dense_heads_loss_forward_f32): bit-identical, one latency-bound launch less per minibatch
+FUSE_LOSS = int(os.environ.get("PPO_AMD_FUSE_LOSS", "1"))
 # uint8 image minibatches are read out of the whole rollout batch through the permutation by the first convolution (and by
 # its weight gradient) instead of being gathered into a second buffer by a launch of its own (0 = gather first)
 GATHER_IN_CONV = int(os.environ.get("PPO_AMD_GATHER_IN_CONV", "1"))
@@ -377,6 +380,7 @@ class DualHeadNet:
         self._chain_split_usable = None  # decided at the first split launch (see _encode_impala)
         self.allow_chain_split = False   # set by a caller that checks chain_split_error() afterwards
         self.obs_index = None  # [B] int32 (device): the next TRAINING forward reads observation i at x[obs_index[i]] (see takes_obs_index)
+        self.loss_tail = None  # arguments of the PPO loss for the next training forward's dense + heads launch (ppo_minibatch)
         self._tail_ptrs = {}  # stack index -> pointer arrays of the fused residual-block kernel
         self.obs_norm = None  # shared ObsNormalizer (set by TVFModel when observation_normalization is on)
         self.grad_ready_hook = None  # callable(stream), see _backward_impala (data-parallel gradient buckets)
@@ -979,7 +983,11 @@ class DualHeadNet:
             ws = self._ws("gemm_ws" + tag, ws_bytes)
             args = (_p(flat), 1, _p(w), _p(self.params["encoder.dense.bias"]), _p(self.w_heads), _p(self.b_heads), 1, _p(h),
                     _p(o), B, sp.flat, sp.hidden_units, self.nh, _p(ws), ws_bytes)
-            if self.act_tail is not None and not train:
+            if train and self.loss_tail is not None:
+                # with the discrete PPO loss on the finished head row (ppo_minibatch set the tail): no loss launch
+                tail, self.loss_tail = self.loss_tail, None
+                self._call("ppo_dense_heads_loss_forward_f32", *args, *tail)
+            elif self.act_tail is not None and not train:
                 # with the rollout's action step (see encode); the recorded launch list keeps the plain form, whose
                 # replay adds the tail of its own env step
                 tail, self.act_tail = self.act_tail, None
@@ -1400,12 +1408,21 @@ class DualHeadNet:
                 grad_scale=float(loss_scale) / B, n_actions=self.n_actions, n_value_heads=self.vh if returns is not None else 0,
                 returns=_p(returns), vf_coef=float(vf_coef), actions_i=_p(actions), old_log_pac=_p(old_log_pac),
                 old_log_policy=_p(old_log_policy), advantages=_p(advantages), eps_clip=float(eps_clip), ent_coef=float(ent_coef))
-        acts, o, B, dheads = self._train_forward(prev_state, index)
+        B = int(index.shape[0]) if index is not None else int(prev_state.shape[0])
         stats = self._buf("loss_stats", (B, 8))
         vh = self.vh if returns is not None else 0
-        self._call("ppo_ppo_loss_f32", _p(o), B, self.nh, self.n_actions, vh, _p(actions), _p(old_log_pac),
-                   _p(old_log_policy), _p(advantages), _p(returns), float(eps_clip), float(ent_coef), float(vf_coef),
-                   float(loss_scale) / B, _p(dheads), _p(stats), _p(index))
+        loss_args = (self.n_actions, vh, _p(actions), _p(old_log_pac), _p(old_log_policy), _p(advantages), _p(returns),
+                     float(eps_clip), float(ent_coef), float(vf_coef), float(loss_scale) / B,
+                     _p(self._buf("dheads", (B, self.nh))), _p(stats), _p(index))
+        # the loss rides on the dense + heads launch of the training forward where that launch exists (IMPALA, relu)
+        self.loss_tail = loss_args if FUSE_LOSS else None
+        try:
+            acts, o, B, dheads = self._train_forward(prev_state, index)
+            fused = FUSE_LOSS and self.loss_tail is None
+        finally:
+            self.loss_tail = None
+        if not fused:
+            self._call("ppo_ppo_loss_f32", _p(o), B, self.nh, *loss_args)
         self.backward(acts, dheads)
         return stats
 

@@ -505,3 +505,40 @@ def test_adam_grad_div_equals_prescaled_gradients():
                                          None, _st()), "adam")
         outs.append(w)
     assert (outs[0] - outs[1]).abs().max().item() < 1e-7
+
+
+@pytest.mark.parametrize("bsz,nA", [(256, 6), (100, 4), (64, 15), (37, 7)])
+def test_dense_heads_with_the_ppo_loss_is_bitwise_the_separate_launches(bsz, nA):
+    """ppo_dense_heads_loss_forward_f32 (the discrete PPO loss on the finished head row, in the finalize launch of a training
+    forward) against ppo_dense_heads_forward_f32 followed by ppo_ppo_loss_f32: heads, d loss / d heads and the statistics
+    rows bit for bit, through a minibatch index, for action counts with a fused form and one without (7)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(bsz * 7 + nA)
+    K, H, vh = 3872, 256, 1
+    NH = 2 * nA + vh
+    Btot = bsz + 50
+    x = torch.randn(bsz, K, generator=g).to(DEV)
+    W = (torch.randn(H, K, generator=g) * 0.02).to(DEV)
+    b = torch.randn(H, generator=g).to(DEV)
+    Wh = (torch.randn(NH, H, generator=g) * 0.1).to(DEV)
+    bh = torch.randn(NH, generator=g).to(DEV)
+    idx = torch.randperm(Btot, generator=g)[:bsz].int().to(DEV)
+    actions = torch.randint(0, nA, (Btot,), generator=g).int().to(DEV)
+    lp = torch.log_softmax(torch.randn(Btot, nA, generator=g), dim=1).to(DEV)
+    pac = lp.gather(1, actions.long()[:, None])[:, 0].contiguous()
+    adv, ret = torch.randn(Btot, generator=g).to(DEV), torch.randn(Btot, vh, generator=g).to(DEV)
+    ws_bytes = lib.ppo_gemm_workspace_bytes(bsz, H, K)
+    ws = torch.empty(max(ws_bytes // 4, 1), device=DEV)
+    h1, o1 = torch.empty(bsz, H, device=DEV), torch.empty(bsz, NH, device=DEV)
+    d1, s1 = torch.full((bsz, NH), float("nan"), device=DEV), torch.full((bsz, 8), float("nan"), device=DEV)
+    _lib.check(lib.ppo_dense_heads_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h1), _p(o1), bsz, K, H, NH, _p(ws),
+                                               ws_bytes, _st()), "dense_heads")
+    loss = (nA, vh, _p(actions), _p(pac), _p(lp), _p(adv), _p(ret), 0.2, 0.01, 0.5, 1.0 / bsz)
+    _lib.check(lib.ppo_ppo_loss_f32(_p(o1), bsz, NH, *loss, _p(d1), _p(s1), _p(idx), _st()), "ppo_loss")
+    h2, o2 = torch.full_like(h1, float("nan")), torch.full_like(o1, float("nan"))
+    d2, s2 = torch.full_like(d1, float("nan")), torch.full_like(s1, float("nan"))
+    _lib.check(lib.ppo_dense_heads_loss_forward_f32(_p(x), 1, _p(W), _p(b), _p(Wh), _p(bh), 1, _p(h2), _p(o2), bsz, K, H, NH, _p(ws),
+                                                    ws_bytes, *loss, _p(d2), _p(s2), _p(idx), _st()), "dense_heads_loss")
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2) and torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(s1, s2)
+    assert torch.isfinite(d2).all() and float(d2.abs().max()) > 0
