@@ -391,6 +391,9 @@ def _describe_call(fn, a):
     if fn in ("ppo_conv3x3_backward_weight_slabs_batch_f32", "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32"):
         k, n, ci, co, h, w = a[5:11]
         return f"conv3x3 wgrad x{k} {ci}->{co} {h}x{w}", k * _conv(n, ci, co, h, w), None
+    if fn == "ppo_conv3x3_backward_weight_slabs_batch_bf16x3":
+        k, n, ci, co, h, w = a[5:11]
+        return f"conv3x3 wgrad x{k} (3 x bf16 MFMA) {ci}->{co} {h}x{w}", k * _conv(n, ci, co, h, w), None
     if fn == "ppo_conv3x3_backward_weight_f32":
         n, ci, co, h, w = a[7:12]
         return f"conv3x3 wgrad {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
@@ -962,7 +965,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if not split else "f32 + bf16x3 (opt-in --precision=%s: the 32-channel residual blocks, forward and "
-                                         "backward-data, as 3 bf16 MFMAs per product with f32 accumulation; everything else f32)" % a.precision,
+                                         "backward-data, and the weight gradients of the 16- / 32-channel float layers as 3 bf16 "
+                                         "MFMAs per product with f32 accumulation; everything else f32)" % a.precision,
         "data": "synthetic",
         "config": {"workload": f"{a.config}: PPO iteration, {A} envs/GPU x {N} steps, obs {tuple(obs_shape)} {obs_kind}, "
                                f"{n_actions} actions, {net_kind} ({model.model_size()} params), "

@@ -215,6 +215,14 @@ int ppo_conv3x3_backward_weight_slabs_batch_f32(const void *const *ins, int in_m
 int ppo_conv3x3_backward_weight_slabs_batch_mixed_f32(const void *const *ins, const int *relu, const float *const *dys,
                                                       void *const *workspaces, size_t workspace_bytes, int count, int n,
                                                       int cin, int cout, int h, int w, int *n_slabs, void *stream);
+/* OPT-IN reduced precision (`--precision=medium|low`, /root/reference train.py:166-178): the same launch with every product
+ * taken as three bf16 MFMAs on (hi, lo) splits of both operands, float32 accumulation (csrc/wgrad_bf16x3.hip; products carry
+ * ~16 bits).  Float32 inputs only (16 or 32 channels: ppo_conv3x3_backward_weight_bf16x3_supported); count 1..5; the slabs
+ * have the layout of the float32 kernels', so ppo_conv3x3_wgrad_reduce_f32 folds them.  db is summed in float32. */
+int ppo_conv3x3_backward_weight_bf16x3_supported(int cin, int cout, int h, int w);
+int ppo_conv3x3_backward_weight_slabs_batch_bf16x3(const float *const *ins, const int *relu, const float *const *dys,
+                                                   void *const *workspaces, size_t workspace_bytes, int count, int n, int cin,
+                                                   int cout, int h, int w, int *n_slabs, void *stream);
 /* A stack's FIRST convolution with its dy taken from the pooled gradient: dy = ppo_maxpool3x3s2_backward_f32(g, argmax)
  * is formed band by band inside the kernel (g [n,cout,h/2,w/2], argmax uint8 likewise), so the pre-pool gradient map
  * never exists in HBM.  Same slabs as the max-pool backward launch followed by ppo_conv3x3_backward_weight_slabs_f32.

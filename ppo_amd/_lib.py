@@ -82,6 +82,8 @@ SIGNATURES = {
     "ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_backward_weight_slabs_batch_f32": (_i, [_vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ppo_conv3x3_backward_weight_bf16x3_supported": (_i, [_i, _i, _i, _i]),
+    "ppo_conv3x3_backward_weight_slabs_batch_bf16x3": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_wgrad_reduce_f32": (_i, [_vp, _i, _vp]),
     "ppo_tanh_forward_f32": (_i, [_vp, _vp, _sz, _vp]),
     "ppo_tanh_backward_f32": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -45,6 +45,9 @@ WGRAD_POOLED_DY = int(os.environ.get("PPO_AMD_WGRAD_POOLED_DY", "1"))
 # net) has its weight gradient formed by that stack's batched launch, as a fifth problem read without the ReLU
 # (ppo_conv3x3_backward_weight_slabs_batch_mixed_f32): one launch less per backward pass (11 - 14 us of fixed cost)
 WGRAD_RIDE = int(os.environ.get("PPO_AMD_WGRAD_RIDE", "1"))
+# --precision=medium|low only: weight gradients of the 16- and 32-channel float layers as split-bf16 products too
+# (csrc/wgrad_bf16x3.hip; 0 keeps them on the exact float32 kernel while the residual blocks stay split).
+SPLIT_WGRAD = int(os.environ.get("PPO_AMD_SPLIT_WGRAD", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -1147,6 +1150,11 @@ class DualHeadNet:
 
         jobs = []  # deferred slab reductions: one launch for all layers at the end of the pass
 
+        def split_wgrad(mode, cin, cout, hh, ww):
+            """--precision=medium|low: this layer's weight gradient as split-bf16 products (csrc/wgrad_bf16x3.hip)."""
+            return self.split_bf16 and SPLIT_WGRAD and WGRAD_BATCH_REDUCE and mode in (IN_NONE, IN_RELU) \
+                and lib.ppo_conv3x3_backward_weight_bf16x3_supported(cin, cout, hh, ww)
+
         def wgrad(x, mode, dy, wname, n, cin, cout, hh, ww, argmax=None):
             """argmax given: dy is the POOLED gradient and the kernel forms max-pool backward itself."""
             nbytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
@@ -1159,6 +1167,11 @@ class DualHeadNet:
                 elif argmax is not None:
                     args_ = ("ppo_conv3x3_backward_weight_slabs_pooled_f32", _p(x), mode, _p(dy), _p(argmax), _p(ws),
                              nbytes, n, cin, cout, hh, ww, ctypes.addressof(n_slabs))
+                elif split_wgrad(mode, cin, cout, hh, ww):
+                    keep = ((ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_int * 1)(int(mode == IN_RELU)),
+                            (ctypes.c_void_p * 1)(dy.data_ptr()), (ctypes.c_void_p * 1)(ws.data_ptr()))
+                    args_ = ("ppo_conv3x3_backward_weight_slabs_batch_bf16x3", keep[0], keep[1], keep[2], keep[3], nbytes, 1, n,
+                             cin, cout, hh, ww, ctypes.addressof(n_slabs))
                 else:
                     args_ = ("ppo_conv3x3_backward_weight_slabs_f32", _p(x), mode, _p(dy), _p(ws), nbytes, n, cin, cout,
                              hh, ww, ctypes.addressof(n_slabs))
@@ -1206,7 +1219,10 @@ class DualHeadNet:
             ins = (ctypes.c_void_p * k)(*[x.data_ptr() for x, _d, _w in problems])
             dys = (ctypes.c_void_p * k)(*[dy.data_ptr() for _x, dy, _w in problems])
             wsp = (ctypes.c_void_p * k)(*[ws.data_ptr() for ws in wss])
-            if k > 4:
+            if split_wgrad(IN_RELU, c, c, hh, ww):
+                args_ = ("ppo_conv3x3_backward_weight_slabs_batch_bf16x3", ins, (ctypes.c_int * k)(*relu), dys, wsp, nbytes, k, n,
+                         c, c, hh, ww, ctypes.addressof(n_slabs))
+            elif k > 4:
                 args_ = ("ppo_conv3x3_backward_weight_slabs_batch_mixed_f32", ins, (ctypes.c_int * k)(*relu), dys, wsp, nbytes, k, n,
                          c, c, hh, ww, ctypes.addressof(n_slabs))
             else:

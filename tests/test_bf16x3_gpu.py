@@ -177,3 +177,85 @@ def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches()
         if scale > 0:
             worst = max(worst, float((grads["medium"][k] - gh).abs().max()) / scale)
     assert 0 < worst <= 1e-3, worst
+
+
+# ------------------------------------------------------------------ split-bf16 weight gradients (csrc/wgrad_bf16x3.hip)
+SPLIT_WG = [(16, 16, 42), (16, 32, 42), (32, 32, 21), (32, 32, 11), (16, 16, 32), (16, 32, 32), (32, 32, 16), (32, 32, 8)]
+
+
+def _split_wgrad(lib, problems, n, cin, cout, hw):
+    """problems = [(x, relu, dy)] -> [(dw, db)] through the batched split launch + the shared slab reduction."""
+    k = len(problems)
+    ws_bytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
+    wss = [torch.full((ws_bytes // 4,), float("nan"), device="cuda") for _ in range(k)]
+    ins = (ctypes.c_void_p * k)(*[p[0].data_ptr() for p in problems])
+    relu = (ctypes.c_int * k)(*[int(p[1]) for p in problems])
+    dys = (ctypes.c_void_p * k)(*[p[2].data_ptr() for p in problems])
+    wsp = (ctypes.c_void_p * k)(*[w.data_ptr() for w in wss])
+    n_slabs = ctypes.c_int(0)
+    _lib.check(lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(ins, relu, dys, wsp, ws_bytes, k, n, cin, cout, hw, hw,
+                                                                  ctypes.addressof(n_slabs), _lib.current_stream()), "split wgrad")
+    assert 1 <= n_slabs.value <= 512
+    outs = [(torch.full((cout, cin, 3, 3), 7.0, device="cuda"), torch.full((cout,), 7.0, device="cuda")) for _ in range(k)]
+    jobs = [_lib.WgradJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr(), n_slabs.value, cin, cout, 0) for ws, (dw, db) in zip(wss, outs)]
+    table = (_lib.WgradJob * k)(*jobs)
+    _lib.check(lib.ppo_conv3x3_wgrad_reduce_f32(ctypes.addressof(table), k, _lib.current_stream()), "reduce")
+    return outs
+
+
+@pytest.mark.parametrize("cin,cout,hw", SPLIT_WG)
+@pytest.mark.parametrize("n", [1, 3, 41, 256])
+def test_split_bf16_weight_gradients_match_float64(cin, cout, hw, n):
+    """dW, db of rl/impala.py's convolutions (autograd of torch.nn.Conv2d) in float64 on the host against the split
+    launch: 2e-5 of the largest entry (products carry ~16 bits, sums are float32; the exact kernel is held to 1e-4 of
+    max against float32 autograd in test_nn_ops_gpu.py, i.e. to summation-order noise).  Five problems in one launch,
+    ReLU'd and raw inputs mixed, as the backward pass issues them."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    assert lib.ppo_conv3x3_backward_weight_bf16x3_supported(cin, cout, hw, hw) == 1
+    g = torch.Generator().manual_seed(cin + cout * 3 + hw * 5 + n)
+    k = 5 if n <= 41 else 2
+    problems = []
+    for i in range(k):
+        x = (torch.randn(n, cin, hw, hw, generator=g) * 1.7).to("cuda")
+        dy = (torch.randn(n, cout, hw, hw, generator=g) * 0.3).to("cuda")
+        problems.append((x, i % 2 == 0, dy))
+    outs = _split_wgrad(lib, problems, n, cin, cout, hw)
+    for (x, relu, dy), (dw, db) in zip(problems, outs):
+        xin = (F.relu(x) if relu else x).double().cpu()
+        w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        rw, rb = torch.autograd.grad(F.conv2d(xin, w, b, padding=1), (w, b), dy.double().cpu())
+        err_w = (dw.double().cpu() - rw).abs().max().item() / rw.abs().max().item()
+        err_b = (db.double().cpu() - rb).abs().max().item() / rb.abs().max().item()
+        assert err_w <= 2e-5 and err_b <= 2e-5, (err_w, err_b)
+
+
+def test_split_bf16_weight_gradient_is_exact_where_bf16_is():
+    """Operands that ARE bf16 values (small integers) with exactly representable sums: the three-term product drops
+    nothing, so the result is the integer one - every tap shift, halo and band boundary lands where it should."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for cin, cout, hw in [(16, 16, 42), (32, 32, 21), (32, 32, 11), (16, 32, 42)]:
+        n = 7
+        x = torch.randint(-3, 4, (n, cin, hw, hw), generator=g).float().to("cuda")
+        dy = torch.randint(-2, 3, (n, cout, hw, hw), generator=g).float().to("cuda")
+        (dw, db), = _split_wgrad(lib, [(x, False, dy)], n, cin, cout, hw)
+        import torch.nn.functional as F
+        w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        rw, rb = torch.autograd.grad(F.conv2d(x.double().cpu(), w, b, padding=1), (w, b), dy.double().cpu())
+        assert torch.equal(dw.double().cpu(), rw) and torch.equal(db.double().cpu(), rb)
+
+
+def test_split_bf16_weight_gradient_rejects_what_it_has_no_kernel_for():
+    lib = _lib.load()
+    assert lib.ppo_conv3x3_backward_weight_bf16x3_supported(4, 16, 84, 84) == 0
+    x = torch.zeros(1, 4, 84, 84, device="cuda")
+    dy = torch.zeros(1, 16, 84, 84, device="cuda")
+    ws = torch.zeros(1 << 20, device="cuda")
+    n_slabs = ctypes.c_int(0)
+    one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())  # noqa: E731
+    rc = lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(one(x), (ctypes.c_int * 1)(0), one(dy), one(ws), ws.numel() * 4, 1, 1, 4,
+                                                            16, 84, 84, ctypes.addressof(n_slabs), _lib.current_stream())
+    assert rc != 0 and b"no kernel" in lib.ppo_last_error()
