@@ -31,6 +31,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4b;
 
 constexpr int kRec = 144;  // bytes per pixel record
+#ifndef PPO_TUNE_W16_NW   // waves x pixel tiles per wave of the 16-channel window kernel (66 tiles at 25 x 42)
+#define PPO_TUNE_W16_NW 12
+#define PPO_TUNE_W16_MT 6
+#endif
 
 template <int C, int H, int W, int MT, int NW>
 struct SplitCfg {
@@ -191,6 +195,164 @@ __global__ __launch_bounds__(NW * 2 * 64) void stack_tail_bf16x3_kernel(SplitTai
     }
 }
 
+// ---- 16 channels (the 42x42 / 32x32 stack): K = 32 is TWO taps x 16 channels, and a map of per-pixel records no longer
+// fits twice (42x42: 2 x 124 KB).  Every image is therefore cut into NWIN row windows, one workgroup each, that RECOMPUTE
+// their halo: a window holds its OWN rows plus 4 rows towards the image's interior (one per layer of the chain), treats
+// its cut edge as zero padding, and stores only rows it owns - a row k layers deep is wrong only within k rows of the cut,
+// which the halo absorbs.  19 % more MFMA work at 42x42 (2 x 25 rows for 42), bought with MFMAs that are 5 x cheaper
+// than the float32 ones; no exchange between workgroups, and a 128-image rollout group fills 256 CUs.
+// Layout: hi and lo are separate planes of dense 32-byte records (16 channels), so the B fragment (lane = pixel l & 15;
+// k = 8 (l >> 4) + j: tap 2 ks + (l >> 5), channels 8 ((l >> 4) & 1) + j) is one ds_read_b128 at a per-lane tap offset;
+// eight consecutive pixels are 64 consecutive banks.  Maps ping-pong as above: 2 x 2 x 27 x 44 x 32 B = 149 KB.
+template <int HI, int W, int NWIN, int R, int NW, int MT>
+struct Split16Cfg {
+    static constexpr int C = 16;
+    static constexpr int OWN = HI / NWIN;                   // rows a window owns (stores)
+    static_assert(HI % NWIN == 0 && (NWIN == 1 ? R == HI : R >= OWN + 4), "a cut needs four halo rows");
+    static constexpr int PW = W + 2, PH = R + 2;
+    static constexpr int NPIX = R * W;
+    static constexpr int MTILES = (NPIX + 15) / 16;
+    static constexpr int PLANE = PW * PH * 32;              // bytes: one of (hi, lo)
+    static constexpr int MAP_BYTES = 2 * PLANE;
+    static constexpr size_t LDS_BYTES = (size_t)2 * MAP_BYTES;
+    static constexpr int KS = 5;                            // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-)
+    static_assert(MTILES <= MT * NW, "every pixel tile has a wave");
+    static_assert(LDS_BYTES <= 160 * 1024, "two maps must fit the CU's LDS");
+};
+
+template <int HI, int W, int NWIN, int R, int NW, int MT, bool BACKWARD>
+__global__ __launch_bounds__(NW * 64) void stack_win16_bf16x3_kernel(SplitTailArgs a)
+{
+    using S = Split16Cfg<HI, W, NWIN, R, NW, MT>;
+    constexpr int C = 16;
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid * 16; i < 2 * S::MAP_BYTES; i += NW * 64 * 16) *reinterpret_cast<uint4 *>(smem_b + i) = uint4{0, 0, 0, 0};
+
+    int rec0[MT], pix[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int p = (wave * MT + m) * 16 + l15;
+        pix[m] = p;
+        const int pc = p < S::NPIX ? p : 0;
+        rec0[m] = ((pc / W) * S::PW + (pc % W)) * 32;
+    }
+    // this lane's tap of each pair and its channel half
+    int tapoff[S::KS];
+#pragma unroll
+    for (int ks = 0; ks < S::KS; ++ks) {
+        const int t = 2 * ks + (g >> 1) < 9 ? 2 * ks + (g >> 1) : 8;  // (the ninth pair's second tap has zero weights)
+        tapoff[ks] = ((t / 3) * S::PW + (t % 3)) * 32 + (g & 1) * 16;
+    }
+    const int ch0 = 4 * g;  // the four output channels of this lane
+    __syncthreads();
+
+    for (int item = blockIdx.x; item < a.n_images * NWIN; item += gridDim.x) {
+        const int img = item / NWIN, win = item % NWIN;
+        const int own0 = win * S::OWN;
+        const int r0 = NWIN == 1 ? 0 : (own0 - 4 < 0 ? 0 : (own0 - 4 > HI - R ? HI - R : own0 - 4));  // first image row of the window
+        const size_t img_off = (size_t)img * C * HI * W + (size_t)r0 * W;
+        auto elem = [&](int m, int r) { return img_off + (size_t)(ch0 + r) * (HI * W) + (pix[m] < S::NPIX ? pix[m] : 0); };
+        auto owned = [&](int m) {
+            const int y = r0 + pix[m] / W;
+            return pix[m] < S::NPIX && y >= own0 && y < own0 + S::OWN;
+        };
+        float xres[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xres[m][r] = a.in[elem(m, r)];
+        auto publish = [&](int map, const float (&v)[MT][4]) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (pix[m] < S::NPIX) {
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        __bf16 h, l;
+                        split2(BACKWARD ? v[m][r] : fmaxf(v[m][r], 0.f), h, l);
+                        hi[r] = h, lo[r] = l;
+                    }
+                    unsigned char *rec = smem_b + map * S::MAP_BYTES + rec0[m] + (S::PW + 1) * 32 + ch0 * 2;
+                    *reinterpret_cast<bf16x4 *>(rec) = hi;
+                    *reinterpret_cast<bf16x4 *>(rec + S::PLANE) = lo;
+                }
+            }
+        };
+        auto store = [&](float *dst, const float (&v)[MT][4]) {
+            if (!dst) return;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (owned(m)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[elem(m, r)] = v[m][r];
+                }
+        };
+        __syncthreads();  // the previous item's last readers are done with map 0
+        publish(0, xres);
+
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            bf16x8 whi[S::KS], wlo[S::KS];
+            const bf16x8 *wl = a.w + (size_t)layer * S::KS * 2 * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < S::KS; ++ks) {
+                whi[ks] = wl[(ks * 2 + 0) * 64];
+                wlo[ks] = wl[(ks * 2 + 1) * 64];
+            }
+            float bias_r[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias_r[r] = BACKWARD ? 0.f : a.bias[layer][ch0 + r];
+            __syncthreads();  // the source map is complete
+            const int odd = layer & 1;
+            const unsigned char *src = smem_b + (odd ? S::MAP_BYTES : 0);
+            f32x4b acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < S::KS; ++ks) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bf16x8 bhi = *reinterpret_cast<const bf16x8 *>(src + rec0[m] + tapoff[ks]);
+                    const bf16x8 blo = *reinterpret_cast<const bf16x8 *>(src + rec0[m] + tapoff[ks] + S::PLANE);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[ks], bhi, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], blo, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], bhi, acc[m], 0, 0, 0);
+                }
+            }
+            float y[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[m][r] = acc[m][r] + bias_r[r];
+            if constexpr (BACKWARD) {
+                float gate[MT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gate[m][r] = a.mask[layer][elem(m, r)];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[m][r] = gate[m][r] > 0.f ? y[m][r] : 0.f;
+            }
+            if (!odd) {
+                publish(1, y);
+                store(a.save[layer], y);
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xres[m][r] = y[m][r] + xres[m][r];
+                if (layer == 1) publish(0, xres);
+                store(a.save[layer], xres);
+            }
+        }
+    }
+}
+
 // weights [cout 32][cin 32][3][3] float32 -> A fragments: lane (row = l & 15, k = 8 (l >> 4) + j).  Forward: row = output
 // channel, k = input channel, tap as stored.  Transposed (backward-data): row = INPUT channel, k = output channel, tap
 // flipped - dX[i] = sum_{o, taps} W[o][i][2 - ky][2 - kx] dY[o] is a forward convolution with those weights.
@@ -199,13 +361,30 @@ struct SplitPackJobs {
     const float *w[kMaxSplitJobs][4];
     __bf16 *packed[kMaxSplitJobs];
     int transposed[kMaxSplitJobs];
+    int channels[kMaxSplitJobs];
     int n;
 };
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const SplitPackJobs jobs)
 {
     const int job = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (layer, ng, tap, lane)
-    if (i >= 4 * 2 * 9 * 64 || job >= jobs.n) return;
+    if (job >= jobs.n) return;
+    if (jobs.channels[job] == 16) {
+        // [layer 4][tap pair 5][hi, lo][lane 64]: row = l & 15, k = 8 (l >> 4) + j = (tap 2 ks + (l >> 5), channel 8 ((l >> 4) & 1) + j)
+        if (i >= 4 * 5 * 64) return;
+        const int lane = i & 63, ks = (i >> 6) % 5, layer = i / (64 * 5);
+        const float *w = jobs.w[job][layer];
+        const int row = lane & 15, gq = lane >> 4, t = 2 * ks + (gq >> 1), c0 = 8 * (gq & 1);
+        __bf16 *hi = jobs.packed[job] + (((size_t)layer * 5 + ks) * 2 + 0) * 64 * 8 + lane * 8;
+        __bf16 *lo = jobs.packed[job] + (((size_t)layer * 5 + ks) * 2 + 1) * 64 * 8 + lane * 8;
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (t < 9) v = jobs.transposed[job] ? w[((size_t)(c0 + j) * 16 + row) * 9 + (8 - t)] : w[((size_t)row * 16 + c0 + j) * 9 + t];
+            split2(v, hi[j], lo[j]);
+        }
+        return;
+    }
+    if (i >= 4 * 2 * 9 * 64) return;
     const int lane = i & 63, t = (i >> 6) % 9, ng = (i / (64 * 9)) & 1, layer = i / (64 * 9 * 2);
     const float *w = jobs.w[job][layer];
     __bf16 *packed = jobs.packed[job];
@@ -236,6 +415,25 @@ int launch_split_tail(const SplitTailArgs &args, hipStream_t st)
     return check_launch("stack_tail_bf16x3_kernel");
 }
 
+template <int HI, int W, int NWIN, int R, int NW, int MT, bool BACKWARD>
+int launch_split_win16(const SplitTailArgs &args, hipStream_t st)
+{
+    using S = Split16Cfg<HI, W, NWIN, R, NW, MT>;
+    auto kern = stack_win16_bf16x3_kernel<HI, W, NWIN, R, NW, MT, BACKWARD>;
+    static bool ready = false;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)S::LDS_BYTES);
+        if (e != hipSuccess) return fail(PPO_E_HIP, "stack_win16_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        ready = true;
+    }
+    const int items = args.n_images * NWIN;
+    const int per_cu = S::LDS_BYTES <= 80 * 1024 ? 2 : 1;
+    const int grid = items < 256 * per_cu ? items : 256 * per_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), S::LDS_BYTES, st, args);
+    return check_launch("stack_win16_bf16x3_kernel");
+}
+
 int split_tail(const char *who, bool backward, const float *in, const void *packed, const float *const *bias_or_mask,
                float *s0, float *s1, float *s2, float *s3, int n_images, int channels, int h, int w, void *stream)
 {
@@ -256,6 +454,9 @@ int split_tail(const char *who, bool backward, const float *in, const void *pack
         return backward ? launch_split_tail<32, 21, 21, 7, 4, true>(args, st) : launch_split_tail<32, 21, 21, 7, 4, false>(args, st);
     if (channels == 32 && h == 11 && w == 11)
         return backward ? launch_split_tail<32, 11, 11, 2, 4, true>(args, st) : launch_split_tail<32, 11, 11, 2, 4, false>(args, st);
+    if (channels == 16 && h == 42 && w == 42)
+        return backward ? launch_split_win16<42, 42, 2, 25, PPO_TUNE_W16_NW, PPO_TUNE_W16_MT, true>(args, st)
+                        : launch_split_win16<42, 42, 2, 25, PPO_TUNE_W16_NW, PPO_TUNE_W16_MT, false>(args, st);
     return fail(PPO_E_INVALID, "%s: no kernel for %d channels at %dx%d", who, channels, h, w);
 }
 
@@ -266,7 +467,7 @@ extern "C" size_t ppo_impala_stack_tail_bf16x3_packed_bytes(void) { return (size
 
 extern "C" int ppo_impala_stack_tail_bf16x3_supported(int channels, int h, int w)
 {
-    return channels == 32 && ((h == 21 && w == 21) || (h == 11 && w == 11));
+    return (channels == 32 && ((h == 21 && w == 21) || (h == 11 && w == 11))) || (channels == 16 && h == 42 && w == 42);
 }
 
 extern "C" int ppo_impala_stack_tail_pack_bf16x3_jobs(const ppo_split_pack_job *jobs, int n_jobs, void *stream)
@@ -278,7 +479,7 @@ extern "C" int ppo_impala_stack_tail_pack_bf16x3_jobs(const ppo_split_pack_job *
     SplitPackJobs t{};
     t.n = n_jobs;
     for (int j = 0; j < n_jobs; ++j) {
-        if (jobs[j].channels != 32) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: 32 channels only");
+        if (jobs[j].channels != 32 && jobs[j].channels != 16) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: 16 or 32 channels");
         if (!jobs[j].packed || !aligned(jobs[j].packed, 16)) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: null or misaligned packed buffer");
         for (int l = 0; l < 4; ++l) {
             if (!jobs[j].weights[l]) return fail(PPO_E_INVALID, "ppo_impala_stack_tail_pack_bf16x3_jobs: null weights");
@@ -286,6 +487,7 @@ extern "C" int ppo_impala_stack_tail_pack_bf16x3_jobs(const ppo_split_pack_job *
         }
         t.packed[j] = static_cast<__bf16 *>(jobs[j].packed);
         t.transposed[j] = jobs[j].transposed;
+        t.channels[j] = jobs[j].channels;
     }
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((4 * 2 * 9 * 64 + 255) / 256, n_jobs), dim3(256), 0, as_stream(stream), t);
     return check_launch("pack_bf16x3_kernel");

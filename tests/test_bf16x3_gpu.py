@@ -24,9 +24,11 @@ def reference(p, ws, bs):
     return q
 
 
-@pytest.mark.parametrize("hw,stack,B", [(21, 1, 9), (11, 2, 9), (21, 1, 300)])
+@pytest.mark.parametrize("hw,stack,B", [(21, 1, 9), (11, 2, 9), (21, 1, 300), (42, 0, 9), (42, 0, 1), (42, 0, 300)])
 def test_split_bf16_blocks_match_float64_within_1e4(hw, stack, B):
+    """(42, 0): the 16-channel stack - two row windows per image that recompute their halo, csrc/stack_bf16x3.hip.)"""
     lib = _lib.load()
+    ch = 16 if stack == 0 else 32
     torch.manual_seed(hw * 100 + B)
     net = models.DualHeadNet("impala", (4, 84, 84), 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     names = [f"encoder.stacks.{stack}.blocks.{bi}.conv{ci}" for bi in range(2) for ci in range(2)]
@@ -36,23 +38,24 @@ def test_split_bf16_blocks_match_float64_within_1e4(hw, stack, B):
         b_.normal_(0, 0.1)  # (zero at initialisation: give the bias path something to carry)
     net.mark_weights_changed()
     net._refresh_packed()
-    p = torch.randn(B, 32, hw, hw, device="cuda") * 1.5
+    p = torch.randn(B, ch, hw, hw, device="cuda") * 1.5
     ref = reference(p.cpu(), [w.cpu() for w in ws], [b_.cpu() for b_ in bs])
     scale = float(ref.abs().max())
     st = _lib.current_stream()
     # exact float32 kernel
-    tail = net._stack_tail_ptrs(stack, 32, hw, hw)
+    tail = net._stack_tail_ptrs(stack, ch, hw, hw)
     q32 = torch.empty_like(p)
-    _lib.check(lib.ppo_impala_stack_tail_forward_f32(p.data_ptr(), tail[0], tail[1], None, None, None, q32.data_ptr(), B, 32,
-                                                     hw, hw, st), "stack_tail f32")
+    q0_32 = torch.empty_like(p) if ch == 16 else None  # (the exact 16-channel form re-reads q0 for its second skip connection)
+    _lib.check(lib.ppo_impala_stack_tail_forward_f32(p.data_ptr(), tail[0], tail[1], None, q0_32.data_ptr() if ch == 16 else None,
+                                                     None, q32.data_ptr(), B, ch, hw, hw, st), "stack_tail f32")
     # split-bf16 kernel
     packed = torch.empty(int(lib.ppo_impala_stack_tail_bf16x3_packed_bytes()), dtype=torch.uint8, device="cuda")
     wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in ws])
     bp = (ctypes.c_void_p * 4)(*[b_.data_ptr() for b_ in bs])
-    _lib.check(lib.ppo_impala_stack_tail_pack_bf16x3(wp, packed.data_ptr(), 32, 0, st), "pack bf16x3")
+    _lib.check(lib.ppo_impala_stack_tail_pack_bf16x3(wp, packed.data_ptr(), ch, 0, st), "pack bf16x3")
     q16 = torch.full_like(p, float("nan"))
     _lib.check(lib.ppo_impala_stack_tail_forward_bf16x3(p.data_ptr(), packed.data_ptr(), bp, None, None, None, q16.data_ptr(), B,
-                                                        32, hw, hw, st), "stack_tail bf16x3")
+                                                        ch, hw, hw, st), "stack_tail bf16x3")
     torch.cuda.synchronize()
     e32 = float((q32.cpu().double() - ref).abs().max()) / scale
     e16 = float((q16.cpu().double() - ref).abs().max()) / scale
@@ -62,41 +65,42 @@ def test_split_bf16_blocks_match_float64_within_1e4(hw, stack, B):
     assert e16 > e32  # (if not, the split path is not what ran)
 
 
-@pytest.mark.parametrize("hw,stack,B", [(21, 1, 37), (11, 2, 37)])
+@pytest.mark.parametrize("hw,stack,B", [(21, 1, 37), (11, 2, 37), (42, 0, 37), (42, 0, 200)])
 def test_split_bf16_training_forward_and_backward_match_the_exact_kernels(hw, stack, B):
     """The training forms: the forward pass that also keeps a0 / q0 / a1 (what the backward pass and the weight gradients
     read), and the gated transposed chain da1, g1, da0, g0 - each map against the exact-float32 kernel's, 1e-4 of its
     largest entry; the gates are the same forward pre-activations on both sides."""
     lib = _lib.load()
+    ch = 16 if stack == 0 else 32
     torch.manual_seed(hw + B)
     net = models.DualHeadNet("impala", (4, 84, 84), 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     net._refresh_packed()
     st = _lib.current_stream()
     fwd_names = [f"encoder.stacks.{stack}.blocks.{bi}.conv{ci}" for bi in range(2) for ci in range(2)]
     bwd_names = [f"encoder.stacks.{stack}.blocks.{bi}.conv{ci}" for bi in (1, 0) for ci in (1, 0)]
-    p = torch.randn(B, 32, hw, hw, device="cuda")
-    g = torch.randn(B, 32, hw, hw, device="cuda")
-    tail = net._stack_tail_ptrs(stack, 32, hw, hw)
-    tail_t = net._stack_tail_bwd_ptrs(stack, 32, hw, hw)
+    p = torch.randn(B, ch, hw, hw, device="cuda")
+    g = torch.randn(B, ch, hw, hw, device="cuda")
+    tail = net._stack_tail_ptrs(stack, ch, hw, hw)
+    tail_t = net._stack_tail_bwd_ptrs(stack, ch, hw, hw)
     exact = [torch.empty_like(p) for _ in range(4)]
-    _lib.check(lib.ppo_impala_stack_tail_forward_f32(p.data_ptr(), tail[0], tail[1], *[t.data_ptr() for t in exact], B, 32, hw, hw,
+    _lib.check(lib.ppo_impala_stack_tail_forward_f32(p.data_ptr(), tail[0], tail[1], *[t.data_ptr() for t in exact], B, ch, hw, hw,
                                                      st), "fwd f32")
     a0, q0, a1, q1 = exact
     masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p.data_ptr())
     gex = [torch.empty_like(p) for _ in range(4)]
-    _lib.check(lib.ppo_impala_stack_tail_backward_f32(g.data_ptr(), tail_t, masks, *[t.data_ptr() for t in gex], B, 32, hw, hw, st),
+    _lib.check(lib.ppo_impala_stack_tail_backward_f32(g.data_ptr(), tail_t, masks, *[t.data_ptr() for t in gex], B, ch, hw, hw, st),
                "bwd f32")
     nbytes = int(lib.ppo_impala_stack_tail_bf16x3_packed_bytes())
     pk, pk_t = (torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2))
     for names, buf, tr in ((fwd_names, pk, 0), (bwd_names, pk_t, 1)):
         wp = (ctypes.c_void_p * 4)(*[net.params[n + ".weight"].data_ptr() for n in names])
-        _lib.check(lib.ppo_impala_stack_tail_pack_bf16x3(wp, buf.data_ptr(), 32, tr, st), "pack")
+        _lib.check(lib.ppo_impala_stack_tail_pack_bf16x3(wp, buf.data_ptr(), ch, tr, st), "pack")
     bp = (ctypes.c_void_p * 4)(*[net.params[n + ".bias"].data_ptr() for n in fwd_names])
     split = [torch.full_like(p, float("nan")) for _ in range(4)]
-    _lib.check(lib.ppo_impala_stack_tail_forward_bf16x3(p.data_ptr(), pk.data_ptr(), bp, *[t.data_ptr() for t in split], B, 32, hw,
+    _lib.check(lib.ppo_impala_stack_tail_forward_bf16x3(p.data_ptr(), pk.data_ptr(), bp, *[t.data_ptr() for t in split], B, ch, hw,
                                                         hw, st), "fwd bf16x3")
     gsp = [torch.full_like(p, float("nan")) for _ in range(4)]
-    _lib.check(lib.ppo_impala_stack_tail_backward_bf16x3(g.data_ptr(), pk_t.data_ptr(), masks, *[t.data_ptr() for t in gsp], B, 32,
+    _lib.check(lib.ppo_impala_stack_tail_backward_bf16x3(g.data_ptr(), pk_t.data_ptr(), masks, *[t.data_ptr() for t in gsp], B, ch,
                                                          hw, hw, st), "bwd bf16x3")
     torch.cuda.synchronize()
     for name, got, want in [(n, a_, b_) for n, a_, b_ in zip(("a0", "q0", "a1", "q1"), split, exact)] + \
@@ -139,7 +143,7 @@ def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches()
         for name, o in (("high", o_hi), ("medium", o_md)):
             err = float(np.abs(o[k].cpu().numpy().reshape(ref.shape) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
             assert err <= 1e-4, (name, k, err)
-    assert calls_md.count("ppo_impala_stack_tail_forward_bf16x3") == 2 and "ppo_impala_stack_tail_forward_bf16x3" not in calls_hi
+    assert calls_md.count("ppo_impala_stack_tail_forward_bf16x3") == 3 and "ppo_impala_stack_tail_forward_bf16x3" not in calls_hi
     assert not torch.equal(o_hi["raw_policy"], o_md["raw_policy"])
     # greedy actions on the 256-observation fixture, fresh head and wide head
     tag = "c2"
@@ -170,7 +174,7 @@ def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches()
         net.ppo_minibatch(x, actions, old_pac, old_lp, adv, ret)
         torch.cuda.synchronize()
         grads[name] = {k: v.clone() for k, v in net.grads.items()}
-    assert calls_md.count("ppo_impala_stack_tail_backward_bf16x3") == 2 and "ppo_impala_stack_tail_backward_bf16x3" not in calls_hi
+    assert calls_md.count("ppo_impala_stack_tail_backward_bf16x3") == 3 and "ppo_impala_stack_tail_backward_bf16x3" not in calls_hi
     worst = 0.0
     for k, gh in grads["high"].items():
         scale = float(gh.abs().max())
