@@ -95,6 +95,9 @@ def parse():
                    help="high (default, THE benchmark): exact float32 everywhere.  low / medium: the reference's flag "
                         "(train.py:166-178 allows TF32 there) - the 32-channel residual blocks run as split-bf16 launches "
                         "(3 bf16 MFMAs per product); the line's dtype says so and it is never the headline")
+    p.add_argument("--no-opt-in", action="store_true",
+                   help="skip the extra leg that times the same workload under --precision=medium (N = 1, IMPALA configs, "
+                        "reported beside the line as opt_in_precision; never `value`)")
     p.add_argument("--no-affinity", action="store_true",
                    help="do not pin the rank (and its env threads) to the cores of its GPU's NUMA node (ppo_amd/affinity.py)")
     p.add_argument("--wall-limit", type=float, default=1500.0,
@@ -1021,11 +1024,40 @@ def main():
                                    "kernel": top["kernel"] + " (largest roofline-bound share of kernel time, "
                                              f"{top['share']:.1%}; per-launch HIP events of the extra iteration)",
                                    "avg_kernel_ms": round(top["avg_us"] * 1e-3, 4), "launches_timed": top["launches"]}
+    if world == 1 and a.precision == "high" and a.config != "humanoid_tvf" and not a.no_opt_in:
+        # The reference's own default is --precision=medium (TF32 convolutions on its GPUs, /root/reference train.py:166-178
+        # as SURVEY.md reads it); here that flag selects the split-bf16 launches (~16-bit products).  Timed on the same
+        # workload in the same process right after the exact-float32 measurement, reported BESIDE the line: `value`
+        # above is exact float32 and stays so.
+        args.precision = "medium"
+        model2 = models.TVFModel(encoder="impala", input_dims=obs_shape, actions=n_actions, device=f"cuda:{local}",
+                                 architecture="single", hidden_units=args.model.hidden_units,
+                                 head_scale=args.model.head_scale, head_bias=args.model.head_bias, precision="medium")
+        runner2 = rollout.Runner(model2, logger.Logger(quiet=True))
+        runner2.vec_env = envs.create_envs_classic(rank=rank, world=world)
+        runner2.reset()
+        for _ in range(max(1, a.warmup)):
+            runner2.generate_rollout(), runner2.calculate_returns(), runner2.train()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            runner2.generate_rollout(), runner2.calculate_returns(), runner2.train()
+        torch.cuda.synchronize()
+        wall2 = time.perf_counter() - t0
+        out["opt_in_precision"] = {
+            "flag": "--precision=medium (the reference's default flag value; bench.py --precision medium gives the full line)",
+            "value": round(N * A * a.steps / wall2, 1), "unit": "env-steps/s", "ms_per_step": round(wall2 / a.steps * 1e3, 2),
+            "steps": a.steps, "split_launches": bool(getattr(model2.policy_net, "split_bf16", False)),
+            "dtype": "f32 + bf16x3: residual blocks (forward, backward-data) and the weight gradients of the 16- / 32-channel "
+                     "float layers as 3 bf16 MFMAs per product, f32 accumulation (~16-bit products); the rest f32",
+            "vs_value": round(N * A * a.steps / wall2 / (env_steps / wall), 3)}
+        args.precision = "high"
     if rank == 0:
         if world == 1 and not a.no_scan:
             out["gae_scan"] = bench_scan(lib, N, a.scan_envs, A)
             out["tvf_returns"] = bench_tvf(a.tvf_heads)
         if world == 1 and not a.no_cpu_baseline:
+            affinity.release()  # the CPU leg gets the whole host, not this rank's NUMA share (13 x slower when pinned)
             out["cpu_baseline"] = (cpu_baseline(N, A, args.policy_opt.epochs, mb, tuple(obs_shape), n_actions)
                                    if a.config != "humanoid_tvf" else
                                    cpu_baseline_mlp(N, A, mb, obs_shape[0], args.model.hidden_units, n_actions, runner.K,

@@ -126,6 +126,30 @@ def pin_rank(local_rank: int, local_world: int, enabled: bool = True) -> Optiona
         if not cpus or set(cpus) == set(allowed):
             return None
         os.sched_setaffinity(0, cpus)
+        global _unpinned_mask
+        _unpinned_mask = set(allowed)
         return cpus
     except OSError:
         return None
+
+
+_unpinned_mask = None  # the mask pin_rank found, for release()
+
+
+def release() -> bool:
+    """Hand every thread of this process the CPU mask it had before pin_rank (threads started while pinned inherited the
+    narrow mask).  For host-only legs that are not part of a rank's hot path and should see the whole machine - bench.py's
+    CPU baseline is timed this way, so that it is the host at its best and not a rank's NUMA share."""
+    if _unpinned_mask is None or not hasattr(os, "sched_setaffinity"):
+        return False
+    ok = True
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, _unpinned_mask)
+        except OSError:
+            ok = False  # (a thread that exited meanwhile)
+    return ok
