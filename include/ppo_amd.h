@@ -666,12 +666,13 @@ int ppo_mlp_train_f32(const float *x, const ppo_mlp_net *net, const ppo_mlp_grad
  *                                       block1.conv1, block1.conv0, block0.conv1, block0.conv0, transposed = 1.
  *   ppo_impala_stack_tail_forward_bf16x3   as ppo_impala_stack_tail_forward_f32: a0 / q0 / a1 nullable (inference)
  *   ppo_impala_stack_tail_backward_bf16x3  as ppo_impala_stack_tail_backward_f32 (masks: a1, q0, a0, p)
- * 32 channels at 21x21 or 11x11 (ppo_impala_stack_tail_bf16x3_supported).
+ * 32 channels at 21x21 or 11x11, 16 channels at 42x42 (ppo_impala_stack_tail_bf16x3_supported; the 16-channel form cuts
+ * every image into two row windows that recompute a four-row halo - no exchange between workgroups).
  */
 typedef struct ppo_split_pack_job {
-    const float *weights[4]; /* raw [32, 32, 3, 3] each, in the order the kernel walks its layers */
+    const float *weights[4]; /* raw [c, c, 3, 3] each, in the order the kernel walks its layers */
     void *packed;            /* ppo_impala_stack_tail_bf16x3_packed_bytes() bytes, 16-byte aligned */
-    int channels;            /* 32 */
+    int channels;            /* 32 or 16 */
     int transposed;          /* 0 forward, 1 backward-data */
 } ppo_split_pack_job;
 size_t ppo_impala_stack_tail_bf16x3_packed_bytes(void);
@@ -683,6 +684,24 @@ int ppo_impala_stack_tail_forward_bf16x3(const float *in, const void *packed, co
                                          float *a1, float *q1, int n_images, int channels, int h, int w, void *stream);
 int ppo_impala_stack_tail_backward_bf16x3(const float *g, const void *packed_t, const float *const *masks, float *da1, float *g1,
                                           float *da0, float *g0, int n_images, int channels, int h, int w, void *stream);
+
+/* One 3x3 convolution (stride 1, zero padding 1) as split-bf16 products, where a convolution is not part of an LDS-resident
+ * chain (csrc/conv_bf16x3.hip): the stack-first convolutions of rl/impala.py:96 (forward: bias, raw input) and their
+ * backward-data form (the same operator on the transposed packing, bias null) under `--precision=medium|low`.
+ *   in [n, cin, h, w] float32 (relu_in != 0: read through max(., 0)), out [n, cout, h, w] float32
+ * cin / cout here are the OPERATOR's: for backward-data pass the layer's (cout, cin) and the packing made with
+ * transposed = 1.  Geometries: ppo_conv3x3_bf16x3_supported. */
+typedef struct ppo_conv_pack_job {
+    const float *weight; /* the layer's raw [cout, cin, 3, 3] */
+    void *packed;        /* ppo_conv3x3_bf16x3_packed_bytes(cin, cout) bytes, 16-byte aligned */
+    int cin, cout;       /* the LAYER's channels (16 or 32 each) */
+    int transposed;      /* 0: fragments of the forward operator, 1: of backward-data */
+} ppo_conv_pack_job;
+int ppo_conv3x3_bf16x3_supported(int cin, int cout, int h, int w);
+size_t ppo_conv3x3_bf16x3_packed_bytes(int cin, int cout);
+int ppo_conv3x3_pack_bf16x3_jobs(const ppo_conv_pack_job *jobs /* host, at most 8 */, int n_jobs, void *stream);
+int ppo_conv3x3_bf16x3(const float *in, int relu_in, const void *packed, const float *bias, float *out, int n, int cin, int cout,
+                       int h, int w, void *stream);
 
 #ifdef __cplusplus
 }

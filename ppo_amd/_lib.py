@@ -112,6 +112,10 @@ SIGNATURES = {
     "ppo_impala_stack_tail_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),
     "ppo_impala_stack_tail_forward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_impala_stack_tail_backward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_bf16x3_supported": (_i, [_i, _i, _i, _i]),
+    "ppo_conv3x3_bf16x3_packed_bytes": (_sz, [_i, _i]),
+    "ppo_conv3x3_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),
+    "ppo_conv3x3_bf16x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_mlp_supported": (_i, [_i, _i, _i]),
     "ppo_mlp_forward_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ppo_mlp_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
@@ -128,6 +132,12 @@ class PackJob(ctypes.Structure):
 class SplitPackJob(ctypes.Structure):
     """ppo_split_pack_job (include/ppo_amd.h)."""
     _fields_ = [("weights", ctypes.c_void_p * 4), ("packed", ctypes.c_void_p), ("channels", ctypes.c_int),
+                ("transposed", ctypes.c_int)]
+
+
+class ConvPackJob(ctypes.Structure):
+    """ppo_conv_pack_job (include/ppo_amd.h)."""
+    _fields_ = [("weight", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
                 ("transposed", ctypes.c_int)]
 
 

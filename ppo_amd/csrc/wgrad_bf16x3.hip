@@ -17,13 +17,16 @@
 // read instruction covers 16 consecutive records (8 per 32-lane half = 64 consecutive banks: conflict-free at any tap
 // shift); K slot (g, j) of the MFMA is record 16 (j >> 2) + 4 g + (j & 3) of the step's 32 - A and B use the same map.
 // Staging: each lane loads four channels of one pixel (dword buffer loads, rows outside the image read 0 through the
-// range check), clamps, splits with v_cvt_pk_bf16_f32 and stores 8 + 8 bytes; a 16-lane group writes four whole records
-// (conflict-free).  The next item's loads are in flight in registers during the K loop.  256-thread workgroups, up to
+// range check), clamps, splits with v_cvt_pk_bf16_f32 and stores 8 + 8 bytes.  A 16-lane group takes 16 consecutive pixels
+// of one channel quad: one cache line per group on the load side at the price of a 4-way bank conflict on the store side
+// (measured 55.2 -> 51.5 us against the conflict-free 4 pixels x 4 quads, which touches four lines per group).  The next item's loads are in flight in registers during the K loop.  256-thread workgroups, up to
 // three per CU (LDS <= 53 KB), so one workgroup's staging runs under another's MFMAs; accumulators stay in registers over
 // all items of a workgroup; db is summed from the float32 dy values while they are staged.
 // Per 32-pixel step and tap: 3 MFMAs (48 cycles) where the float32 kernel issues 8 (256 cycles); what bounds the launch
 // is then HBM (x + dy once, 4 bytes per element), not the matrix pipe.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace ppo {
 namespace {
@@ -51,6 +54,15 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // bit 0 no global loads, bit 1 no LDS stores, bit 2 no K loop
 #ifndef PPO_TUNE_W3_SKIP
 #define PPO_TUNE_W3_SKIP 0
+#endif
+#ifndef PPO_TUNE_W3_MAP
+#define PPO_TUNE_W3_MAP 1
+#endif
+#ifndef PPO_TUNE_W3_TR21   // band heights of 32 -> 32 at 21x21 and 16 -> 32 at 42x42
+#define PPO_TUNE_W3_TR21 7
+#endif
+#ifndef PPO_TUNE_W3_TR42B
+#define PPO_TUNE_W3_TR42B 7
 #endif
 
 template <int CIN, int COUT, int H, int W, int TR>
@@ -115,16 +127,20 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
 
     // ---- staging constants: lane = (pixel lane >> 2 of 16, channel quad lane & 3); wave-load i covers band pixels
     // 64 i + 16 wave + (0..15)
-    const int quad = lane & 3;
+#if PPO_TUNE_W3_MAP == 1  // 16 consecutive pixels of one channel per 16-lane group (one cache line), chunk = lane >> 4
+    const int quad = lane >> 4, pl = lane & 15;
+#else                    // 4 pixels x 4 channel quads per 16-lane group: four whole records per LDS store group
+    const int quad = lane & 3, pl = lane >> 2;
+#endif
     int x_rec[C::XIT], d_rec[C::DIT];  // LDS byte offset of the quad inside an image
 #pragma unroll
     for (int i = 0; i < C::XIT; ++i) {
-        const int p = 64 * i + 16 * wave + (lane >> 2);
+        const int p = 64 * i + 16 * wave + pl;
         x_rec[i] = ((p / W) * C::RW + p % W + 2) * kRecBytes + quad * 8;  // + guard record + halo column
     }
 #pragma unroll
     for (int i = 0; i < C::DIT; ++i) {
-        const int p = 64 * i + 16 * wave + (lane >> 2);
+        const int p = 64 * i + 16 * wave + pl;
         d_rec[i] = ((p / W) * C::RW + p % W + 1) * kRecBytes + quad * 8;
     }
 
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
         const int x0 = (band * TR - 1) * W, d0 = band * TR * W;  // plane offset of the band's first staged pixel
 #pragma unroll
         for (int i = 0; i < C::XIT; ++i) {
-            const int p = 64 * i + 16 * wave + (lane >> 2);
+            const int p = 64 * i + 16 * wave + pl;
             const int gp = x0 + p;
             // (bitwise &, one select, and an opaque result: a short-circuit condition becomes control flow around the loads
             // and every join of it a full s_waitcnt vmcnt(0), common.h)
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
         }
 #pragma unroll
         for (int i = 0; i < C::DIT; ++i) {
-            const int p = 64 * i + 16 * wave + (lane >> 2);
+            const int p = 64 * i + 16 * wave + pl;
             const int gp = d0 + p;
             int base = ((gp < HW) & (p < C::DPIX)) ? (quad * 4 * HW + gp) * 4 : kFarOutside;
             asm volatile("" : "+v"(base));
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
         if (PPO_TUNE_W3_SKIP & 2) return;
 #pragma unroll
         for (int i = 0; i < C::XIT; ++i) {
-            if (64 * i + 64 <= C::XPIX || 64 * i + 16 * wave + (lane >> 2) < C::XPIX) {
+            if (64 * i + 64 <= C::XPIX || 64 * i + 16 * wave + pl < C::XPIX) {
 #pragma unroll
                 for (int gi = 0; gi < C::NGI; ++gi) {
                     float v[4];
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
         }
 #pragma unroll
         for (int i = 0; i < C::DIT; ++i) {
-            if (64 * i + 64 <= C::DPIX || 64 * i + 16 * wave + (lane >> 2) < C::DPIX) {
+            if (64 * i + 64 <= C::DPIX || 64 * i + 16 * wave + pl < C::DPIX) {
 #pragma unroll
                 for (int m = 0; m < C::MT; ++m) {
 #pragma unroll
@@ -265,9 +281,15 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = bsum[m][r];
+#if PPO_TUNE_W3_MAP == 1
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) v += __shfl_xor(v, sh);
+            if (pl == 0) s_bias[wave * COUT + m * 16 + quad * 4 + r] = v;
+#else
 #pragma unroll
             for (int sh = 4; sh < 64; sh <<= 1) v += __shfl_xor(v, sh);
             if (lane < 4) s_bias[wave * COUT + m * 16 + lane * 4 + r] = v;
+#endif
         }
     __syncthreads();
     if (tid < COUT) {
@@ -295,6 +317,12 @@ int launch_split_wgrad(const SplitWgradBatch &b, int count, int n_images, size_t
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), kSplitWaves * 64, C::LDS_BYTES);
         if (e != hipSuccess || occ < 1) return fail(PPO_E_HIP, "conv3x3_wgrad_bf16x3: occupancy query: %s", hipGetErrorString(e));
         per_cu = occ > 4 ? 4 : occ;
+        if (getenv("PPO_AMD_DEBUG_OCCUPANCY")) {
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "conv3x3_wgrad_bf16x3<%d,%d,%d,%d,%d>: occupancy query %d, LDS %d B, %d regs, static LDS %zu\n", CIN, COUT, H, W, TR,
+                    occ, (int)C::LDS_BYTES, fa.numRegs, fa.sharedSizeBytes);
+        }
     }
     // one resident wave of workgroups over all problems of the launch; every workgroup writes one slab
     const int n_items = n_images * C::NB;
@@ -310,8 +338,8 @@ int launch_split_wgrad(const SplitWgradBatch &b, int count, int n_images, size_t
 
 #define PPO_SPLIT_WGRAD_GEOMETRIES(X) \
     X(16, 16, 42, 42, 7)              \
-    X(16, 32, 42, 42, 7)              \
-    X(32, 32, 21, 21, 7)              \
+    X(16, 32, 42, 42, PPO_TUNE_W3_TR42B) \
+    X(32, 32, 21, 21, PPO_TUNE_W3_TR21)  \
     X(32, 32, 11, 11, 11)             \
     X(16, 16, 32, 32, 8)              \
     X(16, 32, 32, 32, 8)              \

@@ -48,6 +48,9 @@ WGRAD_RIDE = int(os.environ.get("PPO_AMD_WGRAD_RIDE", "1"))
 # --precision=medium|low only: weight gradients of the 16- and 32-channel float layers as split-bf16 products too
 # (csrc/wgrad_bf16x3.hip; 0 keeps them on the exact float32 kernel while the residual blocks stay split).
 SPLIT_WGRAD = int(os.environ.get("PPO_AMD_SPLIT_WGRAD", "1"))
+# likewise the stack-first convolutions (forward: split convolution + the max-pool launch instead of the fused float32
+# conv + pool kernel; backward-data): csrc/conv_bf16x3.hip
+SPLIT_CONV = int(os.environ.get("PPO_AMD_SPLIT_CONV", "1"))
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -450,7 +453,7 @@ class DualHeadNet:
         parity test - is exact float32 everywhere.  Buffers: per such stack the forward and the transposed packing of
         its four block convolutions, refreshed by ONE launch behind the float32 re-pack."""
         self.precision = precision
-        self.split_bf16, self._pk16, self._split_jobs = False, {}, None
+        self.split_bf16, self._pk16, self._split_jobs, self._split_conv_jobs = False, {}, None, None
         if precision == "high" or self.encoder_kind != "impala" or self.spec.n_block != 2:
             return
         jobs = []
@@ -469,6 +472,22 @@ class DualHeadNet:
             self._split_jobs = (_lib.SplitPackJob * len(jobs))(*jobs)
             self.split_bf16 = True
             self._packed_dirty = True
+        # the stack-first convolutions that are not part of a chain (csrc/conv_bf16x3.hip): forward and backward-data
+        cjobs = []
+        self._split_conv_jobs = None
+        for si, (cin, cout, h, w, _ho, _wo) in enumerate(self.spec.stacks):
+            if not (self.split_bf16 and SPLIT_CONV and si > 0 and cin in (16, 32) and cout in (16, 32)):
+                continue
+            wname = f"encoder.stacks.{si}.firstconv"
+            nb = int(self.lib.ppo_conv3x3_bf16x3_packed_bytes(cin, cout))
+            for tr, (ci_op, co_op) in ((0, (cin, cout)), (1, (cout, cin))):
+                if not self.lib.ppo_conv3x3_bf16x3_supported(ci_op, co_op, h, w):
+                    continue
+                buf = torch.zeros(nb, dtype=torch.uint8, device=self.device)
+                self._pk16[(wname, tr)] = buf
+                cjobs.append(_lib.ConvPackJob(self.params[wname + ".weight"].data_ptr(), buf.data_ptr(), cin, cout, tr))
+        if cjobs:
+            self._split_conv_jobs = (_lib.ConvPackJob * len(cjobs))(*cjobs)
 
     def _build_mlp_fused(self):
         """The pointer tables of the fused MLP launches (the flat buffers never move)."""
@@ -622,6 +641,8 @@ class DualHeadNet:
                     self._call("ppo_conv3x3_pack_weights_f32", ctypes.addressof(self._pack_table), len(self._pack_table))
                 if self.split_bf16:
                     self._call("ppo_impala_stack_tail_pack_bf16x3_jobs", ctypes.addressof(self._split_jobs), len(self._split_jobs))
+                    if self._split_conv_jobs is not None:
+                        self._call("ppo_conv3x3_pack_bf16x3_jobs", ctypes.addressof(self._split_conv_jobs), len(self._split_conv_jobs))
             finally:
                 self._rec = rec
 
@@ -912,7 +933,13 @@ class DualHeadNet:
                 acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"] = p, a0, q0, a1
                 cur, cur_mode = q1, IN_NONE
                 continue
-            if FUSE_POOL_STACKS >> si & 1:
+            if self.split_bf16 and (wname, 0) in self._pk16 and cur_mode != IN_U8 and cur.dtype == torch.float32:
+                # --precision=low|medium: the stack-first convolution as split-bf16 products, then the max-pool launch
+                c = self._buf(f"{tag}c{si}", (B, cout, h, w))
+                self._call("ppo_conv3x3_bf16x3", _p(cur), int(cur_mode == IN_RELU), _p(self._pk16[(wname, 0)]),
+                           _p(self.params[wname + ".bias"]), _p(c), B, cin, cout, h, w)
+                self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
+            elif FUSE_POOL_STACKS >> si & 1:
                 # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
                 pk = self._pk.get((wname, 0))
                 if si == 0 and index is not None:
@@ -1322,8 +1349,11 @@ class DualHeadNet:
             if si > 0:
                 g = self._buf(f"g{si - 1}_top", (B, cin, hh, ww))
                 fc = f"encoder.stacks.{si}.firstconv"
-                self._call(self._bwd_data_fn(fc), _p(dc), _p(self._bwd_w(fc)),
-                           None, None, _p(g), B, cin, cout, hh, ww)
+                if self.split_bf16 and (fc, 1) in self._pk16:
+                    self._call("ppo_conv3x3_bf16x3", _p(dc), 0, _p(self._pk16[(fc, 1)]), None, _p(g), B, cout, cin, hh, ww)
+                else:
+                    self._call(self._bwd_data_fn(fc), _p(dc), _p(self._bwd_w(fc)),
+                               None, None, _p(g), B, cin, cout, hh, ww)
         flush_carry()
         if jobs:
             table = (_lib.WgradJob * len(jobs))(*jobs)

@@ -113,7 +113,7 @@ def test_split_bf16_training_forward_and_backward_match_the_exact_kernels(hw, st
 def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches():
     """`--precision=medium` (DualHeadNet(precision=...)): the same reference fixtures as the exact path - forward within
     1e-4 of the reference's largest output, greedy actions index-exact on the 256-observation fixture (both heads), every
-    parameter gradient of one PPO minibatch within 1e-3 of its largest entry - with the split launches really taken,
+    parameter gradient of one PPO minibatch within 2e-3 of its largest entry - with the split launches really taken,
     forward and backward, and `high` (the default) untouched by any of it."""
     import hashlib
     import json
@@ -156,8 +156,12 @@ def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches()
             md.params["policy_head.bias"].copy_(torch.from_numpy(z[f"{tag}_wide_head_bias"]).cuda())
         got = md.forward(xd, policy_temperature=0.0)["argmax_policy"].argmax(1).cpu().numpy()
         want, margin = z[f"{tag}_{prefix}greedy_actions"], z[f"{tag}_{prefix}logit_margin"]
-        decided = margin > 1e-5
-        assert np.array_equal(got[decided], want[decided]), prefix
+        # the exact path decides every observation whose top-two logit margin exceeds 1e-5; the split path's logits carry
+        # up to 1e-4 of the largest output (asserted above), so it is held to the observations decided by more than that
+        decided = margin > 1e-4 * max(1.0, float(np.abs(g["fwd_raw_policy"]).max()))
+        assert decided.mean() > 0.9, prefix
+        wrong = got != want
+        assert not (wrong & decided).any(), (prefix, margin[wrong])
     md.params["policy_head.weight"].copy_(hi.params["policy_head.weight"])
     md.params["policy_head.bias"].copy_(hi.params["policy_head.bias"])
     # one PPO minibatch: every gradient of the split path against the exact path's (itself pinned to the reference's)
@@ -180,7 +184,11 @@ def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches()
         scale = float(gh.abs().max())
         if scale > 0:
             worst = max(worst, float((grads["medium"][k] - gh).abs().max()) / scale)
-    assert 0 < worst <= 1e-3, worst
+    # (2e-3: with the stack-first convolutions split as well, pre-pool values move by ~1e-5 of their scale and a max-pool
+    # argmax or ReLU gate that was a near-tie routes its gradient elsewhere - a discrete change, 1.4e-3 of the largest entry of
+    # encoder.stacks.1.firstconv.weight on this 8-observation batch, 6e-4 in l2; tools/medium_grad_errors.py lists them per
+    # switch.  The weight-gradient kernels themselves add nothing measurable: 4.72e-4 with and without them.)
+    assert 0 < worst <= 2e-3, worst
 
 
 # ------------------------------------------------------------------ split-bf16 weight gradients (csrc/wgrad_bf16x3.hip)
@@ -263,3 +271,57 @@ def test_split_bf16_weight_gradient_rejects_what_it_has_no_kernel_for():
     rc = lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(one(x), (ctypes.c_int * 1)(0), one(dy), one(ws), ws.numel() * 4, 1, 1, 4,
                                                             16, 84, 84, ctypes.addressof(n_slabs), _lib.current_stream())
     assert rc != 0 and b"no kernel" in lib.ppo_last_error()
+
+
+# ------------------------------------------------------------------ one split-bf16 convolution (csrc/conv_bf16x3.hip)
+def _pack_conv(lib, w, transposed):
+    cout, cin = w.shape[:2]
+    buf = torch.zeros(int(lib.ppo_conv3x3_bf16x3_packed_bytes(cin, cout)), dtype=torch.uint8, device="cuda")
+    job = (_lib.ConvPackJob * 1)(_lib.ConvPackJob(w.data_ptr(), buf.data_ptr(), cin, cout, transposed))
+    _lib.check(lib.ppo_conv3x3_pack_bf16x3_jobs(ctypes.addressof(job), 1, _lib.current_stream()), "pack conv")
+    return buf
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(16, 32, 42), (32, 32, 21), (16, 32, 32), (32, 32, 16)])
+@pytest.mark.parametrize("n", [1, 5, 130])
+def test_split_bf16_single_convolution_forward_and_backward_data_match_float64(cin, cout, hw, n):
+    """The stack-first convolution of rl/impala.py:96 (torch.nn.Conv2d, padding 1) and its gradient with respect to the
+    input, float64 on the host, against the split launch: 2e-5 of the largest entry.  Backward-data is the same operator on
+    the transposed packing with the layer's (cout, cin) as its (input, output) channels."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    assert lib.ppo_conv3x3_bf16x3_supported(cin, cout, hw, hw) == 1 and lib.ppo_conv3x3_bf16x3_supported(cout, cin, hw, hw) == 1
+    g = torch.Generator().manual_seed(cin * 3 + cout + hw + n)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.2).to("cuda")
+    b = torch.randn(cout, generator=g).to("cuda")
+    x = (torch.randn(n, cin, hw, hw, generator=g) * 1.3).to("cuda")
+    dy = torch.randn(n, cout, hw, hw, generator=g).to("cuda")
+    st = _lib.current_stream()
+    for relu in (0, 1):
+        y = torch.full((n, cout, hw, hw), float("nan"), device="cuda")
+        _lib.check(lib.ppo_conv3x3_bf16x3(x.data_ptr(), relu, _pack_conv(lib, w, 0).data_ptr(), b.data_ptr(), y.data_ptr(), n, cin, cout,
+                                          hw, hw, st), "conv bf16x3")
+        xin = F.relu(x) if relu else x
+        ref = F.conv2d(xin.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+        err = float((y.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-5, ("forward", relu, err)
+    dx = torch.full((n, cin, hw, hw), float("nan"), device="cuda")
+    _lib.check(lib.ppo_conv3x3_bf16x3(dy.data_ptr(), 0, _pack_conv(lib, w, 1).data_ptr(), None, dx.data_ptr(), n, cout, cin, hw, hw, st),
+               "conv bf16x3 transposed")
+    ref = F.conv_transpose2d(dy.double().cpu(), w.double().cpu(), padding=1)
+    err = float((dx.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, ("backward-data", err)
+
+
+def test_split_bf16_single_convolution_is_exact_on_small_integers():
+    lib = _lib.load()
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    for cin, cout, hw in [(16, 32, 42), (32, 32, 21)]:
+        n = 3
+        w = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float().to("cuda")
+        x = torch.randint(-3, 4, (n, cin, hw, hw), generator=g).float().to("cuda")
+        y = torch.empty(n, cout, hw, hw, device="cuda")
+        _lib.check(lib.ppo_conv3x3_bf16x3(x.data_ptr(), 0, _pack_conv(lib, w, 0).data_ptr(), None, y.data_ptr(), n, cin, cout, hw, hw,
+                                          _lib.current_stream()), "conv")
+        assert torch.equal(y.cpu().double(), F.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1))
