@@ -369,6 +369,8 @@ def _batch_of(fn, a):
         return a[7]
     if fn == "ppo_conv3x3_bf16x3":
         return a[5]
+    if fn == "ppo_conv3x3_pool_bf16x3":
+        return a[6]
     if fn in ("ppo_dense_heads_forward_f32", "ppo_dense_heads_act_forward_f32", "ppo_dense_heads_loss_forward_f32"):
         return a[9]
     if fn == "ppo_conv3x3_block_forward_packed_f32":
@@ -396,6 +398,9 @@ def _describe_call(fn, a):
     if fn in ("ppo_conv3x3_backward_weight_slabs_batch_f32", "ppo_conv3x3_backward_weight_slabs_batch_mixed_f32"):
         k, n, ci, co, h, w = a[5:11]
         return f"conv3x3 wgrad x{k} {ci}->{co} {h}x{w}", k * _conv(n, ci, co, h, w), None
+    if fn == "ppo_conv3x3_pool_bf16x3":
+        n, ci, co, h, w = a[6:11]
+        return f"conv3x3+maxpool fwd (3 x bf16 MFMA) {ci}->{co} {h}x{w}", _conv(n, ci, co, h, w), None
     if fn == "ppo_conv3x3_bf16x3":
         n, ci, co, h, w = a[5:10]
         kind = "fwd" if a[3] is not None else "bwd-data"

@@ -702,6 +702,12 @@ size_t ppo_conv3x3_bf16x3_packed_bytes(int cin, int cout);
 int ppo_conv3x3_pack_bf16x3_jobs(const ppo_conv_pack_job *jobs /* host, at most 8 */, int n_jobs, void *stream);
 int ppo_conv3x3_bf16x3(const float *in, int relu_in, const void *packed, const float *bias, float *out, int n, int cin, int cout,
                        int h, int w, void *stream);
+/* The same convolution followed by the 3x3 / stride 2 / pad 1 max-pool of rl/impala.py:105 in one launch: out and argmax are
+ * [n, cout, (h+1)/2, (w+1)/2]; argmax (nullable) is ppo_maxpool3x3s2_forward_f32's record (winning tap ky * 3 + kx, ties to
+ * the first tap), so ppo_maxpool3x3s2_backward_f32 reads it.  The pre-pool map never reaches HBM.  Forward packing only. */
+int ppo_conv3x3_pool_bf16x3_supported(int cin, int cout, int h, int w);
+int ppo_conv3x3_pool_bf16x3(const float *in, int relu_in, const void *packed, const float *bias, float *out, uint8_t *argmax, int n,
+                            int cin, int cout, int h, int w, void *stream);
 
 #ifdef __cplusplus
 }

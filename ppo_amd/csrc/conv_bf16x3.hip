@@ -26,16 +26,24 @@ constexpr int kFarOutsideC = (int)0x80000000u;  // a byte offset beyond the desc
 
 constexpr int cmaxc(int a, int b) { return a > b ? a : b; }
 
-template <int CI, int CO, int H, int W, int TR>
+template <int CI, int CO, int H, int W, int TR, bool POOL = false>
 struct SplitConvCfg {
     static_assert((CI == 16 || CI == 32) && (CO == 16 || CO == 32), "16 or 32 channels");
     static constexpr int NG = CI / 16, MT = CO / 16;
     static constexpr int KS = CI == 32 ? 9 : 5;               // K steps: a tap of 32 channels, or a pair of taps of 16
     static constexpr int RW = W + 2;
-    static constexpr int NB = (H + TR - 1) / TR;
+    // POOL (3x3 / stride 2 / pad 1 max-pool of the result, F.max_pool2d at rl/impala.py:105): a band is PR pooled rows =
+    // the 2 PR + 1 pre-pool rows they cover (one row recomputed between neighbouring bands), parked in LDS as float32
+    static_assert(!POOL || TR % 2 == 1, "a pooled band covers 2 PR + 1 convolution rows");
+    static constexpr int PR = (TR - 1) / 2;
+    static constexpr int HO = (H + 1) / 2, WO = (W + 1) / 2;
+    static constexpr int NB = POOL ? (HO + PR - 1) / PR : (H + TR - 1) / TR;
     static constexpr int XREC = (TR + 2) * RW + 2;
     static constexpr int PLANE = XREC * 32;                   // bytes of one (group, hi | lo) plane
-    static constexpr int LDS_BYTES = NG * 2 * PLANE;
+    static constexpr int X_BYTES = NG * 2 * PLANE;
+    static constexpr int PSTR = CO + 4;                        // floats per pre-pool pixel: 36 / 20 banks apart, 16-byte accesses conflict-free
+    static constexpr int PRE_BYTES = POOL ? TR * W * PSTR * 4 : 0;
+    static constexpr int LDS_BYTES = X_BYTES + PRE_BYTES;
     static constexpr int XPIX = (TR + 2) * W;                 // pixels staged per channel and band
     static constexpr int XIT = (XPIX + 63) / 64;
     static constexpr int NT = (TR * W + 15) / 16;             // output pixel tiles of a band
@@ -47,7 +55,8 @@ struct SplitConvArgs {
     const float *in;     // [n, CI, H, W]
     const bf16x8 *w;     // [MT][KS][hi, lo][lane 64] fragments of 8 bf16
     const float *bias;   // [CO] or null
-    float *out;          // [n, CO, H, W]
+    float *out;          // [n, CO, H, W]; POOL: [n, CO, HO, WO]
+    uint8_t *argmax;     // POOL: [n, CO, HO, WO] the winning tap ky * 3 + kx (ppo_maxpool3x3s2_forward_f32's record), nullable
     float floor;         // lower clamp of the input on load: 0 = ReLU, -inf = raw
     int n_images;
 };
@@ -64,17 +73,17 @@ __device__ __forceinline__ void store_split4c(unsigned char *p, int lo_off, cons
     *reinterpret_cast<bf16x4 *>(p + lo_off) = lo;
 }
 
-template <int CI, int CO, int H, int W, int TR>
+template <int CI, int CO, int H, int W, int TR, bool POOL>
 __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitConvArgs a)
 {
-    using C = SplitConvCfg<CI, CO, H, W, TR>;
+    using C = SplitConvCfg<CI, CO, H, W, TR, POOL>;
     constexpr int HW = H * W;
     extern __shared__ __align__(16) unsigned char smem_c[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = wave % C::MT, pw = wave / C::MT;
 
-    for (int i = tid * 16; i < C::LDS_BYTES; i += kConvWaves * 64 * 16) *reinterpret_cast<uint4 *>(smem_c + i) = uint4{0, 0, 0, 0};
+    for (int i = tid * 16; i < C::X_BYTES; i += kConvWaves * 64 * 16) *reinterpret_cast<uint4 *>(smem_c + i) = uint4{0, 0, 0, 0};
 
     // ---- this wave's A fragments, once
     bf16x8 whi[C::KS], wlo[C::KS];
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitCo
     auto issue = [&](int item) {
         const int img = item / C::NB, band = item % C::NB;
         const __amdgpu_buffer_rsrc_t xb = buffer_of(a.in + (size_t)img * CI * HW);
-        const int x0 = (band * TR - 1) * W;
+        const int x0 = ((POOL ? 2 * C::PR * band - 1 : band * TR) - 1) * W;  // first input row = first output row - 1
 #pragma unroll
         for (int i = 0; i < C::XIT; ++i) {
             const int p = 64 * i + 16 * wave + pl;
@@ -173,18 +182,68 @@ __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitCo
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], bhi, acc[t], 0, 0, 0);
             }
         }
-        // ---- outputs: lane = pixel l15 of the tile x channels ch0 + r
         const int img = item / C::NB, band = item % C::NB;
-        float *__restrict__ dst = a.out + (size_t)img * CO * HW + (size_t)ch0 * HW + band * TR * W;
-        const int left = HW - band * TR * W;  // pixels of the image from this band's first one on (a last, shorter band)
+        if constexpr (!POOL) {
+            // ---- outputs: lane = pixel l15 of the tile x channels ch0 + r
+            float *__restrict__ dst = a.out + (size_t)img * CO * HW + (size_t)ch0 * HW + band * TR * W;
+            const int left = HW - band * TR * W;  // pixels of the image from this band's first one on (a last, shorter band)
 #pragma unroll
-        for (int t = 0; t < C::TPW; ++t) {
-            if (pix[t] < TR * W && pix[t] < left) {
+            for (int t = 0; t < C::TPW; ++t) {
+                if (pix[t] < TR * W && pix[t] < left) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(size_t)r * HW + pix[t]] = acc[t][r] + bias_r[r];
+                    for (int r = 0; r < 4; ++r) dst[(size_t)r * HW + pix[t]] = acc[t][r] + bias_r[r];
+                }
             }
+            __syncthreads();  // the band's readers are done
+        } else {
+            // ---- the band's pre-pool rows to LDS, pixel-major [row][x][channel] (a lane's four channels are one 16-byte store),
+            // then the 3x3 / stride 2 windows over them, four channels per thread
+            float *s_pre = reinterpret_cast<float *>(smem_c + C::X_BYTES);
+#pragma unroll
+            for (int t = 0; t < C::TPW; ++t) {
+                if (pix[t] < TR * W)
+                    *reinterpret_cast<float4 *>(s_pre + pix[t] * C::PSTR + ch0) =
+                        make_float4(acc[t][0] + bias_r[0], acc[t][1] + bias_r[1], acc[t][2] + bias_r[2], acc[t][3] + bias_r[3]);
+            }
+            __syncthreads();  // pre-pool rows complete; every wave is through with the input planes
+            const int yf = 2 * C::PR * band - 1;  // image row of the band's first pre-pool row
+            constexpr int Q = CO / 4;
+            for (int o = tid; o < Q * C::PR * C::WO; o += kConvWaves * 64) {
+                const int c4 = o % Q, pos = o / Q;
+                const int oyl = pos / C::WO, ox = pos % C::WO, oy = C::PR * band + oyl;
+                if (oy >= C::HO) continue;
+                float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                int best_tap[4] = {0, 0, 0, 0};
+                bool found = false;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ly = 2 * oyl + ky, iy = yf + ly;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = 2 * ox - 1 + kx;
+                        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                            const float4 v4 = *reinterpret_cast<const float4 *>(s_pre + (ly * W + ix) * C::PSTR + c4 * 4);
+                            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (!found || v[r] > best[r] || v[r] != v[r]) {  // strict '>' scan: ties go to the first tap, as pool.hip / PyTorch
+                                    best[r] = v[r];
+                                    best_tap[r] = ky * 3 + kx;
+                                }
+                            }
+                            found = true;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t at = ((size_t)img * CO + c4 * 4 + r) * (C::HO * C::WO) + (size_t)oy * C::WO + ox;
+                    a.out[at] = best[r];
+                    if (a.argmax) a.argmax[at] = (uint8_t)best_tap[r];
+                }
+            }
+            // (no barrier here: the next item's pre-pool stores come after its own "band is complete" barrier)
         }
-        __syncthreads();  // the band's readers are done
     }
 }
 
@@ -222,11 +281,11 @@ __global__ __launch_bounds__(256) void conv_pack_bf16x3_kernel(const ConvPackJob
     }
 }
 
-template <int CI, int CO, int H, int W, int TR>
+template <int CI, int CO, int H, int W, int TR, bool POOL = false>
 int launch_split_conv(const SplitConvArgs &args, hipStream_t st)
 {
-    using C = SplitConvCfg<CI, CO, H, W, TR>;
-    auto kern = conv3x3_bf16x3_kernel<CI, CO, H, W, TR>;
+    using C = SplitConvCfg<CI, CO, H, W, TR, POOL>;
+    auto kern = conv3x3_bf16x3_kernel<CI, CO, H, W, TR, POOL>;
     static int per_cu = 0;
     if (!per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -251,6 +310,12 @@ int launch_split_conv(const SplitConvArgs &args, hipStream_t st)
     X(16, 32, 32, 32, 8)             \
     X(32, 16, 32, 32, 8)             \
     X(32, 32, 16, 16, 8)
+// with the max-pool: (input channels, output channels, h, w, 2 x pooled rows per band + 1)
+#define PPO_SPLIT_CONV_POOL_GEOMETRIES(X) \
+    X(16, 32, 42, 42, 7)                  \
+    X(32, 32, 21, 21, 7)                  \
+    X(16, 32, 32, 32, 9)                  \
+    X(32, 32, 16, 16, 9)
 
 }  // namespace
 }  // namespace ppo
@@ -302,11 +367,39 @@ extern "C" int ppo_conv3x3_bf16x3(const float *in, int relu_in, const void *pack
     if (!in || !packed || !out || !aligned(packed, 16)) return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
     if ((size_t)n * (cin > cout ? cin : cout) * h * w * sizeof(float) >= kBufferBytes)
         return fail(PPO_E_INVALID, "%s: tensor beyond the 2 GB a buffer descriptor spans", who);
-    SplitConvArgs args{in, static_cast<const bf16x8 *>(packed), bias, out, relu_in ? 0.f : -__builtin_inff(), n};
+    SplitConvArgs args{in, static_cast<const bf16x8 *>(packed), bias, out, nullptr, relu_in ? 0.f : -__builtin_inff(), n};
 #define X(CI, CO, HH, WW, TR)                          \
     if (cin == CI && cout == CO && h == HH && w == WW) \
         return launch_split_conv<CI, CO, HH, WW, TR>(args, as_stream(stream));
     PPO_SPLIT_CONV_GEOMETRIES(X)
+#undef X
+    return fail(PPO_E_INVALID, "%s: no kernel for %d -> %d channels at %dx%d", who, cin, cout, h, w);
+}
+
+extern "C" int ppo_conv3x3_pool_bf16x3_supported(int cin, int cout, int h, int w)
+{
+#define X(CI, CO, HH, WW, TR) \
+    if (cin == CI && cout == CO && h == HH && w == WW) return 1;
+    PPO_SPLIT_CONV_POOL_GEOMETRIES(X)
+#undef X
+    return 0;
+}
+
+extern "C" int ppo_conv3x3_pool_bf16x3(const float *in, int relu_in, const void *packed, const float *bias, float *out, uint8_t *argmax,
+                                       int n, int cin, int cout, int h, int w, void *stream)
+{
+    using namespace ppo;
+    const char *who = "ppo_conv3x3_pool_bf16x3";
+    if (n < 0) return fail(PPO_E_INVALID, "%s: negative batch", who);
+    if (n == 0) return PPO_OK;
+    if (!in || !packed || !out || !aligned(packed, 16)) return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
+    if ((size_t)n * (cin > cout ? cin : cout) * h * w * sizeof(float) >= kBufferBytes)
+        return fail(PPO_E_INVALID, "%s: tensor beyond the 2 GB a buffer descriptor spans", who);
+    SplitConvArgs args{in, static_cast<const bf16x8 *>(packed), bias, out, argmax, relu_in ? 0.f : -__builtin_inff(), n};
+#define X(CI, CO, HH, WW, TR)                          \
+    if (cin == CI && cout == CO && h == HH && w == WW) \
+        return launch_split_conv<CI, CO, HH, WW, TR, true>(args, as_stream(stream));
+    PPO_SPLIT_CONV_POOL_GEOMETRIES(X)
 #undef X
     return fail(PPO_E_INVALID, "%s: no kernel for %d -> %d channels at %dx%d", who, cin, cout, h, w);
 }

@@ -51,6 +51,7 @@ SPLIT_WGRAD = int(os.environ.get("PPO_AMD_SPLIT_WGRAD", "1"))
 # likewise the stack-first convolutions (forward: split convolution + the max-pool launch instead of the fused float32
 # conv + pool kernel; backward-data): csrc/conv_bf16x3.hip
 SPLIT_CONV = int(os.environ.get("PPO_AMD_SPLIT_CONV", "1"))
+SPLIT_CONV_POOL = int(os.environ.get("PPO_AMD_SPLIT_CONV_POOL", "1"))  # ... with the max-pool inside the launch
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -935,10 +936,14 @@ class DualHeadNet:
                 continue
             if self.split_bf16 and (wname, 0) in self._pk16 and cur_mode != IN_U8 and cur.dtype == torch.float32:
                 # --precision=low|medium: the stack-first convolution as split-bf16 products, then the max-pool launch
-                c = self._buf(f"{tag}c{si}", (B, cout, h, w))
-                self._call("ppo_conv3x3_bf16x3", _p(cur), int(cur_mode == IN_RELU), _p(self._pk16[(wname, 0)]),
-                           _p(self.params[wname + ".bias"]), _p(c), B, cin, cout, h, w)
-                self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
+                if SPLIT_CONV_POOL and self.lib.ppo_conv3x3_pool_bf16x3_supported(cin, cout, h, w):
+                    self._call("ppo_conv3x3_pool_bf16x3", _p(cur), int(cur_mode == IN_RELU), _p(self._pk16[(wname, 0)]),
+                               _p(self.params[wname + ".bias"]), _p(p), _p(idx), B, cin, cout, h, w)
+                else:
+                    c = self._buf(f"{tag}c{si}", (B, cout, h, w))
+                    self._call("ppo_conv3x3_bf16x3", _p(cur), int(cur_mode == IN_RELU), _p(self._pk16[(wname, 0)]),
+                               _p(self.params[wname + ".bias"]), _p(c), B, cin, cout, h, w)
+                    self._call("ppo_maxpool3x3s2_forward_f32", _p(c), _p(p), _p(idx), B, cout, h, w)
             elif FUSE_POOL_STACKS >> si & 1:
                 # stack-first convolution + max-pool, fused: the pre-pool map never reaches HBM
                 pk = self._pk.get((wname, 0))

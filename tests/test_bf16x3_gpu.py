@@ -325,3 +325,31 @@ def test_split_bf16_single_convolution_is_exact_on_small_integers():
         _lib.check(lib.ppo_conv3x3_bf16x3(x.data_ptr(), 0, _pack_conv(lib, w, 0).data_ptr(), None, y.data_ptr(), n, cin, cout, hw, hw,
                                           _lib.current_stream()), "conv")
         assert torch.equal(y.cpu().double(), F.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1))
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(16, 32, 42), (32, 32, 21), (16, 32, 32), (32, 32, 16)])
+@pytest.mark.parametrize("n", [1, 130])
+def test_split_bf16_convolution_with_the_max_pool_inside_is_the_two_launches(cin, cout, hw, n):
+    """ppo_conv3x3_pool_bf16x3 against ppo_conv3x3_bf16x3 followed by ppo_maxpool3x3s2_forward_f32 (itself pinned to
+    F.max_pool2d in test_nn_ops_gpu.py): the pooled map and the argmax record, identical bits - the convolution part is
+    the same instruction stream per output pixel, the pooling the same strict-'>' scan."""
+    lib = _lib.load()
+    assert lib.ppo_conv3x3_pool_bf16x3_supported(cin, cout, hw, hw) == 1
+    g = torch.Generator().manual_seed(cin + cout + hw * 3 + n)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.2).to("cuda")
+    b = torch.randn(cout, generator=g).to("cuda")
+    x = torch.randn(n, cin, hw, hw, generator=g).to("cuda")
+    x[:, :, 0::7, :] = 0.0  # flat stretches: ties inside pooling windows
+    pk = _pack_conv(lib, w, 0)
+    st = _lib.current_stream()
+    ho = (hw + 1) // 2
+    c = torch.empty(n, cout, hw, hw, device="cuda")
+    p2, i2 = torch.empty(n, cout, ho, ho, device="cuda"), torch.empty(n, cout, ho, ho, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ppo_conv3x3_bf16x3(x.data_ptr(), 1, pk.data_ptr(), b.data_ptr(), c.data_ptr(), n, cin, cout, hw, hw, st), "conv")
+    _lib.check(lib.ppo_maxpool3x3s2_forward_f32(c.data_ptr(), p2.data_ptr(), i2.data_ptr(), n, cout, hw, hw, st), "pool")
+    p1 = torch.full_like(p2, float("nan"))
+    i1 = torch.full_like(i2, 255)
+    _lib.check(lib.ppo_conv3x3_pool_bf16x3(x.data_ptr(), 1, pk.data_ptr(), b.data_ptr(), p1.data_ptr(), i1.data_ptr(), n, cin, cout, hw,
+                                           hw, st), "conv + pool")
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(i1, i2)
