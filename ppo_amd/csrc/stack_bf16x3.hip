@@ -454,6 +454,13 @@ int split_tail(const char *who, bool backward, const float *in, const void *pack
         return backward ? launch_split_tail<32, 21, 21, 7, 4, true>(args, st) : launch_split_tail<32, 21, 21, 7, 4, false>(args, st);
     if (channels == 32 && h == 11 && w == 11)
         return backward ? launch_split_tail<32, 11, 11, 2, 4, true>(args, st) : launch_split_tail<32, 11, 11, 2, 4, false>(args, st);
+    // the procgen-shaped net (64x64 observations: 32x32, 16x16 and 8x8 maps)
+    if (channels == 32 && h == 16 && w == 16)
+        return backward ? launch_split_tail<32, 16, 16, 4, 4, true>(args, st) : launch_split_tail<32, 16, 16, 4, 4, false>(args, st);
+    if (channels == 32 && h == 8 && w == 8)
+        return backward ? launch_split_tail<32, 8, 8, 1, 4, true>(args, st) : launch_split_tail<32, 8, 8, 1, 4, false>(args, st);
+    if (channels == 16 && h == 32 && w == 32)
+        return backward ? launch_split_win16<32, 32, 2, 20, 10, 4, true>(args, st) : launch_split_win16<32, 32, 2, 20, 10, 4, false>(args, st);
     if (channels == 16 && h == 42 && w == 42)
         return backward ? launch_split_win16<42, 42, 2, 25, PPO_TUNE_W16_NW, PPO_TUNE_W16_MT, true>(args, st)
                         : launch_split_win16<42, 42, 2, 25, PPO_TUNE_W16_NW, PPO_TUNE_W16_MT, false>(args, st);
@@ -467,7 +474,8 @@ extern "C" size_t ppo_impala_stack_tail_bf16x3_packed_bytes(void) { return (size
 
 extern "C" int ppo_impala_stack_tail_bf16x3_supported(int channels, int h, int w)
 {
-    return (channels == 32 && ((h == 21 && w == 21) || (h == 11 && w == 11))) || (channels == 16 && h == 42 && w == 42);
+    return (channels == 32 && ((h == 21 && w == 21) || (h == 11 && w == 11) || (h == 16 && w == 16) || (h == 8 && w == 8))) ||
+           (channels == 16 && ((h == 42 && w == 42) || (h == 32 && w == 32)));
 }
 
 extern "C" int ppo_impala_stack_tail_pack_bf16x3_jobs(const ppo_split_pack_job *jobs, int n_jobs, void *stream)

@@ -24,13 +24,15 @@ def reference(p, ws, bs):
     return q
 
 
-@pytest.mark.parametrize("hw,stack,B", [(21, 1, 9), (11, 2, 9), (21, 1, 300), (42, 0, 9), (42, 0, 1), (42, 0, 300)])
+@pytest.mark.parametrize("hw,stack,B", [(21, 1, 9), (11, 2, 9), (21, 1, 300), (42, 0, 9), (42, 0, 1), (42, 0, 300),
+                                        (32, 0, 9), (32, 0, 300), (16, 1, 9), (8, 2, 9)])
 def test_split_bf16_blocks_match_float64_within_1e4(hw, stack, B):
     """(42, 0): the 16-channel stack - two row windows per image that recompute their halo, csrc/stack_bf16x3.hip.)"""
     lib = _lib.load()
     ch = 16 if stack == 0 else 32
     torch.manual_seed(hw * 100 + B)
-    net = models.DualHeadNet("impala", (4, 84, 84), 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
+    dims = (3, 64, 64) if hw in (32, 16, 8) else (4, 84, 84)  # the procgen-shaped net's maps / the Atari-shaped net's
+    net = models.DualHeadNet("impala", dims, 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     names = [f"encoder.stacks.{stack}.blocks.{bi}.conv{ci}" for bi in range(2) for ci in range(2)]
     ws = [net.params[n + ".weight"] for n in names]
     bs = [net.params[n + ".bias"] for n in names]
@@ -65,7 +67,7 @@ def test_split_bf16_blocks_match_float64_within_1e4(hw, stack, B):
     assert e16 > e32  # (if not, the split path is not what ran)
 
 
-@pytest.mark.parametrize("hw,stack,B", [(21, 1, 37), (11, 2, 37), (42, 0, 37), (42, 0, 200)])
+@pytest.mark.parametrize("hw,stack,B", [(21, 1, 37), (11, 2, 37), (42, 0, 37), (42, 0, 200), (32, 0, 37), (16, 1, 37), (8, 2, 37)])
 def test_split_bf16_training_forward_and_backward_match_the_exact_kernels(hw, stack, B):
     """The training forms: the forward pass that also keeps a0 / q0 / a1 (what the backward pass and the weight gradients
     read), and the gated transposed chain da1, g1, da0, g0 - each map against the exact-float32 kernel's, 1e-4 of its
@@ -73,7 +75,8 @@ def test_split_bf16_training_forward_and_backward_match_the_exact_kernels(hw, st
     lib = _lib.load()
     ch = 16 if stack == 0 else 32
     torch.manual_seed(hw + B)
-    net = models.DualHeadNet("impala", (4, 84, 84), 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
+    dims = (3, 64, 64) if hw in (32, 16, 8) else (4, 84, 84)
+    net = models.DualHeadNet("impala", dims, 6, hidden_units=256, head_scale=0.1, head_bias=True, device="cuda")
     net._refresh_packed()
     st = _lib.current_stream()
     fwd_names = [f"encoder.stacks.{stack}.blocks.{bi}.conv{ci}" for bi in range(2) for ci in range(2)]
