@@ -978,9 +978,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if not split else "f32 + bf16x3 (opt-in --precision=%s: the 32-channel residual blocks, forward and "
-                                         "backward-data, and the weight gradients of the 16- / 32-channel float layers as 3 bf16 "
-                                         "MFMAs per product with f32 accumulation; everything else f32)" % a.precision,
+        "dtype": "f32" if not split else "f32 + bf16x3 (opt-in --precision=%s: every 16- / 32-channel convolution - residual blocks, "
+                                         "stack-first convolutions + max-pool; forward, backward-data, weight gradients - as 3 bf16 "
+                                         "MFMAs per product with f32 accumulation; the uint8 first layer, dense layer, heads, losses, "
+                                         "Adam f32)" % a.precision,
         "data": "synthetic",
         "config": {"workload": f"{a.config}: PPO iteration, {A} envs/GPU x {N} steps, obs {tuple(obs_shape)} {obs_kind}, "
                                f"{n_actions} actions, {net_kind} ({model.model_size()} params), "
@@ -1059,8 +1060,9 @@ def main():
             "flag": "--precision=medium (the reference's default flag value; bench.py --precision medium gives the full line)",
             "value": round(N * A * a.steps / wall2, 1), "unit": "env-steps/s", "ms_per_step": round(wall2 / a.steps * 1e3, 2),
             "steps": a.steps, "split_launches": bool(getattr(model2.policy_net, "split_bf16", False)),
-            "dtype": "f32 + bf16x3: residual blocks (forward, backward-data) and the weight gradients of the 16- / 32-channel "
-                     "float layers as 3 bf16 MFMAs per product, f32 accumulation (~16-bit products); the rest f32",
+            "dtype": "f32 + bf16x3: every 16- / 32-channel convolution (residual blocks, stack-first convolutions + max-pool; forward, "
+                     "backward-data, weight gradients) as 3 bf16 MFMAs per product with f32 accumulation (~16-bit products); the uint8 "
+                     "first layer, dense layer, heads, losses, Adam f32",
             "vs_value": round(N * A * a.steps / wall2 / (env_steps / wall), 3)}
         args.precision = "high"
     if rank == 0:
