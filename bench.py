@@ -365,8 +365,11 @@ def _batch_of(fn, a):
         return a[-4]
     if fn == "ppo_impala_stack_chain_split_forward_f32":
         return a[8]
-    if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3"):
+    if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3",
+              "ppo_impala_stack_tail_backward_signs_bf16x3"):
         return a[7]
+    if fn == "ppo_impala_stack_tail_forward_signs_bf16x3":
+        return a[8]
     if fn == "ppo_conv3x3_bf16x3":
         return a[5]
     if fn == "ppo_conv3x3_pool_bf16x3":
@@ -414,8 +417,9 @@ def _describe_call(fn, a):
     if fn == "ppo_impala_stack_tail_forward_f32":
         n, c, h, w = a[7:11]
         return f"stack blocks fwd (4 conv) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
-    if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3"):
-        n, c, h, w = a[7:11]
+    if fn in ("ppo_impala_stack_tail_forward_bf16x3", "ppo_impala_stack_tail_backward_bf16x3",
+              "ppo_impala_stack_tail_forward_signs_bf16x3", "ppo_impala_stack_tail_backward_signs_bf16x3"):
+        n, c, h, w = a[8:12] if fn == "ppo_impala_stack_tail_forward_signs_bf16x3" else a[7:11]
         kind = "fwd" if "forward" in fn else "bwd-data"
         return f"stack blocks {kind} (4 conv, 3 x bf16 MFMA) {c}ch {h}x{w}", 4 * _conv(n, c, c, h, w), None
     if fn == "ppo_impala_stack_tail_backward_f32":

@@ -684,6 +684,17 @@ int ppo_impala_stack_tail_forward_bf16x3(const float *in, const void *packed, co
                                          float *a1, float *q1, int n_images, int channels, int h, int w, void *stream);
 int ppo_impala_stack_tail_backward_bf16x3(const float *g, const void *packed_t, const float *const *masks, float *da1, float *g1,
                                           float *da0, float *g0, int n_images, int channels, int h, int w, void *stream);
+/* The same two launches with the ReLU gates as SIGN MAPS: signs = host array of 4 device buffers [n, channels / 4, h, w] uint8
+ * (ppo_impala_stack_tail_bf16x3_sign_bytes each), bit r of a byte = (channel 4 k + r of that pixel > 0), in the order of `masks`
+ * (a1, q0, a0, p).  The forward launch writes them beside its float32 maps (which the weight gradients still read); the
+ * backward launch reads them INSTEAD of the four float32 gate maps: 1 byte per 4 elements instead of 16 - its HBM traffic
+ * drops from 9 maps to 5.  Same results as the float-gated launch, bit for bit. */
+size_t ppo_impala_stack_tail_bf16x3_sign_bytes(int n_images, int channels, int h, int w);
+int ppo_impala_stack_tail_forward_signs_bf16x3(const float *in, const void *packed, const float *const *biases, float *a0, float *q0,
+                                               float *a1, float *q1, uint8_t *const *signs, int n_images, int channels, int h, int w,
+                                               void *stream);
+int ppo_impala_stack_tail_backward_signs_bf16x3(const float *g, const void *packed_t, const uint8_t *const *signs, float *da1, float *g1,
+                                                float *da0, float *g0, int n_images, int channels, int h, int w, void *stream);
 
 /* One 3x3 convolution (stride 1, zero padding 1) as split-bf16 products, where a convolution is not part of an LDS-resident
  * chain (csrc/conv_bf16x3.hip): the stack-first convolutions of rl/impala.py:96 (forward: bias, raw input) and their

@@ -112,6 +112,9 @@ SIGNATURES = {
     "ppo_impala_stack_tail_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),
     "ppo_impala_stack_tail_forward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_impala_stack_tail_backward_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_impala_stack_tail_bf16x3_sign_bytes": (_sz, [_i, _i, _i, _i]),
+    "ppo_impala_stack_tail_forward_signs_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_impala_stack_tail_backward_signs_bf16x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_bf16x3_supported": (_i, [_i, _i, _i, _i]),
     "ppo_conv3x3_bf16x3_packed_bytes": (_sz, [_i, _i]),
     "ppo_conv3x3_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),

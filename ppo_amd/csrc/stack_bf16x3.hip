@@ -57,6 +57,10 @@ struct SplitTailArgs {
     const float *mask[4];    // backward only: the forward pre-activation that gates each layer's output (a1, q0, a0, p)
     float *save[4];          // forward: a0, q0, a1, q1 (the last required, the others nullable: inference keeps q1 only)
                              // backward: da1, g1, da0, g0 (all required: the weight gradients read them)
+    uint8_t *sign[4];        // SIGN MAPS [n, C / 4, H, W]: bit r of a byte = (channel 4 k + r of that pixel > 0), in the order of
+                             // `mask` (a1, q0, a0, p).  Forward: written when non-null; backward: read INSTEAD of `mask` when
+                             // non-null - the gates are 1 byte per 4 elements instead of 16 (the backward chain's HBM traffic
+                             // is 9 maps otherwise, 4 of them read only for their sign)
     int n_images;
 };
 
@@ -94,6 +98,14 @@ __global__ __launch_bounds__(NW * 2 * 64) void stack_tail_bf16x3_kernel(SplitTai
     for (int img = blockIdx.x; img < a.n_images; img += gridDim.x) {
         const size_t img_off = (size_t)img * C * H * W;
         auto elem = [&](int m, int r) { return img_off + (size_t)(ch0 + r) * (H * W) + (pix[m] < S::NPIX ? pix[m] : 0); };
+        auto sidx = [&](int m) { return ((size_t)img * (C / 4) + ch0 / 4) * (H * W) + (pix[m] < S::NPIX ? pix[m] : 0); };
+        auto put_signs = [&](uint8_t *dst, const float (&v)[MT][4]) {
+            if (!dst) return;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (pix[m] < S::NPIX)
+                    dst[sidx(m)] = (uint8_t)((v[m][0] > 0.f) | ((v[m][1] > 0.f) << 1) | ((v[m][2] > 0.f) << 2) | ((v[m][3] > 0.f) << 3));
+        };
         // ---- the input map: float32 into the lanes that own it (pixel l15 of tile m, channels ch0 + r); it is the residual
         // stream from here on, its (ReLU'd: forward) split goes to map 0
         float xres[MT][4];
@@ -130,6 +142,7 @@ __global__ __launch_bounds__(NW * 2 * 64) void stack_tail_bf16x3_kernel(SplitTai
         };
         __syncthreads();  // the previous image's last readers are done with map 0
         publish(0, xres);
+        if constexpr (!BACKWARD) put_signs(a.sign[3], xres);
 
 #pragma unroll 1
         for (int layer = 0; layer < 4; ++layer) {
@@ -169,20 +182,32 @@ __global__ __launch_bounds__(NW * 2 * 64) void stack_tail_bf16x3_kernel(SplitTai
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[m][r] = acc[m][r] + bias_r[r];
             if constexpr (BACKWARD) {
-                // the ReLU gate of this layer's output: its forward pre-activation (all loads first, then the selects)
-                float gate[MT][4];
+                // the ReLU gate of this layer's output: its forward pre-activation (all loads first, then the selects), or its
+                // sign map
+                if (a.sign[layer]) {
+                    unsigned bits[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m) bits[m] = a.sign[layer][sidx(m)];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gate[m][r] = a.mask[layer][elem(m, r)];
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                        for (int r = 0; r < 4; ++r) y[m][r] = (bits[m] >> r) & 1u ? y[m][r] : 0.f;
+                } else {
+                    float gate[MT][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[m][r] = gate[m][r] > 0.f ? y[m][r] : 0.f;
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gate[m][r] = a.mask[layer][elem(m, r)];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[m][r] = gate[m][r] > 0.f ? y[m][r] : 0.f;
+                }
             }
             if (!odd) {
                 publish(1, y);  // the intermediate map is only ever a convolution input: its split is all that is kept
                 store(a.save[layer], y);
+                if constexpr (!BACKWARD) put_signs(a.sign[2 - layer], y);  // layer 0 -> a0 (sign[2]), layer 2 -> a1 (sign[0])
             } else {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -190,6 +215,8 @@ __global__ __launch_bounds__(NW * 2 * 64) void stack_tail_bf16x3_kernel(SplitTai
                     for (int r = 0; r < 4; ++r) xres[m][r] = y[m][r] + xres[m][r];
                 if (layer == 1) publish(0, xres);  // (map 0's last readers - layer 0 - passed this layer's barrier)
                 store(a.save[layer], xres);
+                if constexpr (!BACKWARD)
+                    if (layer == 1) put_signs(a.sign[1], xres);  // q0
             }
         }
     }
@@ -259,6 +286,15 @@ __global__ __launch_bounds__(NW * 64) void stack_win16_bf16x3_kernel(SplitTailAr
             const int y = r0 + pix[m] / W;
             return pix[m] < S::NPIX && y >= own0 && y < own0 + S::OWN;
         };
+        // sign maps cover the image: a window reads its halo rows' bytes and writes the rows it owns
+        auto sidx = [&](int m) { return ((size_t)img * (C / 4) + g) * (HI * W) + (size_t)r0 * W + (pix[m] < S::NPIX ? pix[m] : 0); };
+        auto put_signs = [&](uint8_t *dst, const float (&v)[MT][4]) {
+            if (!dst) return;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (owned(m))
+                    dst[sidx(m)] = (uint8_t)((v[m][0] > 0.f) | ((v[m][1] > 0.f) << 1) | ((v[m][2] > 0.f) << 2) | ((v[m][3] > 0.f) << 3));
+        };
         float xres[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -292,6 +328,7 @@ __global__ __launch_bounds__(NW * 64) void stack_win16_bf16x3_kernel(SplitTailAr
         };
         __syncthreads();  // the previous item's last readers are done with map 0
         publish(0, xres);
+        if constexpr (!BACKWARD) put_signs(a.sign[3], xres);
 
 #pragma unroll 1
         for (int layer = 0; layer < 4; ++layer) {
@@ -328,19 +365,30 @@ __global__ __launch_bounds__(NW * 64) void stack_win16_bf16x3_kernel(SplitTailAr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[m][r] = acc[m][r] + bias_r[r];
             if constexpr (BACKWARD) {
-                float gate[MT][4];
+                if (a.sign[layer]) {
+                    unsigned bits[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m) bits[m] = a.sign[layer][sidx(m)];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gate[m][r] = a.mask[layer][elem(m, r)];
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                        for (int r = 0; r < 4; ++r) y[m][r] = (bits[m] >> r) & 1u ? y[m][r] : 0.f;
+                } else {
+                    float gate[MT][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[m][r] = gate[m][r] > 0.f ? y[m][r] : 0.f;
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gate[m][r] = a.mask[layer][elem(m, r)];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[m][r] = gate[m][r] > 0.f ? y[m][r] : 0.f;
+                }
             }
             if (!odd) {
                 publish(1, y);
                 store(a.save[layer], y);
+                if constexpr (!BACKWARD) put_signs(a.sign[2 - layer], y);
             } else {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -348,6 +396,8 @@ __global__ __launch_bounds__(NW * 64) void stack_win16_bf16x3_kernel(SplitTailAr
                     for (int r = 0; r < 4; ++r) xres[m][r] = y[m][r] + xres[m][r];
                 if (layer == 1) publish(0, xres);
                 store(a.save[layer], xres);
+                if constexpr (!BACKWARD)
+                    if (layer == 1) put_signs(a.sign[1], xres);
             }
         }
     }
@@ -435,15 +485,23 @@ int launch_split_win16(const SplitTailArgs &args, hipStream_t st)
 }
 
 int split_tail(const char *who, bool backward, const float *in, const void *packed, const float *const *bias_or_mask,
-               float *s0, float *s1, float *s2, float *s3, int n_images, int channels, int h, int w, void *stream)
+               float *s0, float *s1, float *s2, float *s3, int n_images, int channels, int h, int w, void *stream,
+               uint8_t *const *signs = nullptr)
 {
     if (n_images < 0) return fail(PPO_E_INVALID, "%s: negative batch", who);
     if (n_images == 0) return PPO_OK;
-    if (!in || !packed || !bias_or_mask || !s3 || !aligned(packed, 16)) return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
+    if (!in || !packed || (!bias_or_mask && !(backward && signs)) || !s3 || !aligned(packed, 16))
+        return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
     if (backward && (!s0 || !s1 || !s2)) return fail(PPO_E_INVALID, "%s: the backward pass writes all four gradient maps", who);
     SplitTailArgs args;
     args.in = in, args.w = static_cast<const bf16x8 *>(packed), args.n_images = n_images;
     for (int l = 0; l < 4; ++l) {
+        args.sign[l] = signs ? signs[l] : nullptr;
+        if (backward && signs) {  // the sign maps stand in for the float gate maps
+            if (!signs[l]) return fail(PPO_E_INVALID, "%s: null sign map of layer %d", who, l);
+            args.bias[l] = args.mask[l] = nullptr;
+            continue;
+        }
         if (!bias_or_mask[l]) return fail(PPO_E_INVALID, "%s: null bias / mask of layer %d", who, l);
         args.bias[l] = backward ? nullptr : bias_or_mask[l];
         args.mask[l] = backward ? bias_or_mask[l] : nullptr;
@@ -523,4 +581,27 @@ extern "C" int ppo_impala_stack_tail_backward_bf16x3(const float *g, const void 
 {
     return ppo::split_tail("ppo_impala_stack_tail_backward_bf16x3", true, g, packed_t, masks, da1, g1, da0, g0, n_images, channels,
                            h, w, stream);
+}
+
+extern "C" size_t ppo_impala_stack_tail_bf16x3_sign_bytes(int n_images, int channels, int h, int w)
+{
+    return (size_t)n_images * (channels / 4) * h * w;
+}
+
+extern "C" int ppo_impala_stack_tail_forward_signs_bf16x3(const float *in, const void *packed, const float *const *biases, float *a0,
+                                                          float *q0, float *a1, float *q1, uint8_t *const *signs, int n_images,
+                                                          int channels, int h, int w, void *stream)
+{
+    if (!signs) return ppo::fail(PPO_E_INVALID, "ppo_impala_stack_tail_forward_signs_bf16x3: null sign table");
+    return ppo::split_tail("ppo_impala_stack_tail_forward_signs_bf16x3", false, in, packed, biases, a0, q0, a1, q1, n_images, channels,
+                           h, w, stream, signs);
+}
+
+extern "C" int ppo_impala_stack_tail_backward_signs_bf16x3(const float *g, const void *packed_t, const uint8_t *const *signs, float *da1,
+                                                           float *g1, float *da0, float *g0, int n_images, int channels, int h, int w,
+                                                           void *stream)
+{
+    if (!signs) return ppo::fail(PPO_E_INVALID, "ppo_impala_stack_tail_backward_signs_bf16x3: null sign table");
+    return ppo::split_tail("ppo_impala_stack_tail_backward_signs_bf16x3", true, g, packed_t, nullptr, da1, g1, da0, g0, n_images,
+                           channels, h, w, stream, const_cast<uint8_t *const *>(signs));
 }

@@ -52,6 +52,7 @@ SPLIT_WGRAD = int(os.environ.get("PPO_AMD_SPLIT_WGRAD", "1"))
 # conv + pool kernel; backward-data): csrc/conv_bf16x3.hip
 SPLIT_CONV = int(os.environ.get("PPO_AMD_SPLIT_CONV", "1"))
 SPLIT_CONV_POOL = int(os.environ.get("PPO_AMD_SPLIT_CONV_POOL", "1"))  # ... with the max-pool inside the launch
+SPLIT_SIGNS = int(os.environ.get("PPO_AMD_SPLIT_SIGNS", "1"))  # the split backward chains read 1-bit gates written by the forward
 # convolutions read their MFMA A operand from a pre-packed copy of the weights, refreshed by one launch after every
 # optimiser step (0 = every kernel stages the raw tensor through LDS itself); bit-identical either way
 PACKED_WEIGHTS = int(os.environ.get("PPO_AMD_PACKED_WEIGHTS", "1"))
@@ -965,9 +966,16 @@ class DualHeadNet:
                 # --precision=low|medium: this stack's residual blocks as the split-bf16 launch
                 names = [f"{tag}a{si}_0", f"{tag}q{si}_0", f"{tag}a{si}_1", f"{tag}q{si}_1"]
                 a0, q0, a1, q1 = (self._buf(nm, (B, cout, ho, wo)) for nm in names)
-                self._call("ppo_impala_stack_tail_forward_bf16x3", _p(p), _p(self._pk16[(si, 0)]), self._pk16[(si, "bias")],
-                           _p(a0) if train else None, _p(q0) if train else None, _p(a1) if train else None, _p(q1), B, cout,
-                           ho, wo)
+                if train and SPLIT_SIGNS and cout == 16:  # (measured: 82 -> 61 us for the 16-channel backward chain; nothing at 32 channels)
+                    # the backward chain's gates as sign maps (1 byte per 4 elements instead of 4 float32 maps read for a sign)
+                    sg = [self._buf(f"{tag}sg{si}_{k}", (B, cout // 4, ho, wo), torch.uint8) for k in range(4)]
+                    acts[f"signs{si}"] = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in sg])
+                    self._call("ppo_impala_stack_tail_forward_signs_bf16x3", _p(p), _p(self._pk16[(si, 0)]), self._pk16[(si, "bias")],
+                               _p(a0), _p(q0), _p(a1), _p(q1), acts[f"signs{si}"], B, cout, ho, wo)
+                else:
+                    self._call("ppo_impala_stack_tail_forward_bf16x3", _p(p), _p(self._pk16[(si, 0)]), self._pk16[(si, "bias")],
+                               _p(a0) if train else None, _p(q0) if train else None, _p(a1) if train else None, _p(q1), B, cout,
+                               ho, wo)
                 acts[f"q{si}_0_in"], acts[f"a{si}_0"], acts[f"q{si}_1_in"], acts[f"a{si}_1"] = p, a0, q0, a1
                 cur, cur_mode = q1, IN_NONE
                 continue
@@ -1303,7 +1311,10 @@ class DualHeadNet:
                 da1, g1, da0, g0 = (self._buf(nm, (B, cout, ho, wo)) for nm in
                                     (f"g{si}_1_da", f"g{si}_1_in", f"g{si}_0_da", f"g{si}_0_in"))
                 masks = (ctypes.c_void_p * 4)(a1.data_ptr(), q0.data_ptr(), a0.data_ptr(), p_in.data_ptr())
-                if split:
+                if split and acts.get(f"signs{si}") is not None:
+                    self._call("ppo_impala_stack_tail_backward_signs_bf16x3", _p(g), _p(self._pk16[(si, 1)]), acts[f"signs{si}"],
+                               _p(da1), _p(g1), _p(da0), _p(g0), B, cout, ho, wo)
+                elif split:
                     self._call("ppo_impala_stack_tail_backward_bf16x3", _p(g), _p(self._pk16[(si, 1)]), masks, _p(da1), _p(g1),
                                _p(da0), _p(g0), B, cout, ho, wo)
                 else:

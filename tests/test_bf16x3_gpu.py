@@ -105,7 +105,31 @@ def test_split_bf16_training_forward_and_backward_match_the_exact_kernels(hw, st
     gsp = [torch.full_like(p, float("nan")) for _ in range(4)]
     _lib.check(lib.ppo_impala_stack_tail_backward_bf16x3(g.data_ptr(), pk_t.data_ptr(), masks, *[t.data_ptr() for t in gsp], B, ch,
                                                          hw, hw, st), "bwd bf16x3")
+    # the same two launches with the gates as sign maps (written by the forward, read by the backward instead of the four
+    # float32 maps): identical bits, and the bytes are the signs of (a1, q0, a0, p)
+    nb = int(lib.ppo_impala_stack_tail_bf16x3_sign_bytes(B, ch, hw, hw))
+    assert nb == B * (ch // 4) * hw * hw
+    signs = [torch.full((nb,), 255, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    sp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in signs])
+    split2 = [torch.full_like(p, float("nan")) for _ in range(4)]
+    _lib.check(lib.ppo_impala_stack_tail_forward_signs_bf16x3(p.data_ptr(), pk.data_ptr(), bp, *[t.data_ptr() for t in split2], sp, B, ch,
+                                                              hw, hw, st), "fwd signs")
+    gsp2 = [torch.full_like(p, float("nan")) for _ in range(4)]
+    _lib.check(lib.ppo_impala_stack_tail_backward_signs_bf16x3(g.data_ptr(), pk_t.data_ptr(), sp, *[t.data_ptr() for t in gsp2], B, ch,
+                                                               hw, hw, st), "bwd signs")
+    # (float-gated twin on the SPLIT forward's own maps: `gsp` above is gated by the exact kernel's, whose near-zero
+    # entries may differ in sign)
+    masks2 = (ctypes.c_void_p * 4)(split[2].data_ptr(), split[1].data_ptr(), split[0].data_ptr(), p.data_ptr())
+    gsp_f = [torch.full_like(p, float("nan")) for _ in range(4)]
+    _lib.check(lib.ppo_impala_stack_tail_backward_bf16x3(g.data_ptr(), pk_t.data_ptr(), masks2, *[t.data_ptr() for t in gsp_f], B, ch,
+                                                         hw, hw, st), "bwd bf16x3, own gates")
     torch.cuda.synchronize()
+    for a_, b_ in zip(split + gsp_f, split2 + gsp2):
+        assert torch.equal(a_, b_)
+    for sg, src in zip(signs, (split[2], split[1], split[0], p)):  # a1, q0, a0, p
+        bits = (src > 0).view(B, ch // 4, 4, hw, hw).to(torch.uint8)
+        want_b = (bits[:, :, 0] | (bits[:, :, 1] << 1) | (bits[:, :, 2] << 2) | (bits[:, :, 3] << 3)).reshape(-1)
+        assert torch.equal(sg, want_b)
     for name, got, want in [(n, a_, b_) for n, a_, b_ in zip(("a0", "q0", "a1", "q1"), split, exact)] + \
                            [(n, a_, b_) for n, a_, b_ in zip(("da1", "g1", "da0", "g0"), gsp, gex)]:
         err = float((got - want).abs().max()) / float(want.abs().max())
@@ -181,7 +205,9 @@ def test_precision_flag_runs_the_reference_fixtures_through_the_split_launches()
         net.ppo_minibatch(x, actions, old_pac, old_lp, adv, ret)
         torch.cuda.synchronize()
         grads[name] = {k: v.clone() for k, v in net.grads.items()}
-    assert calls_md.count("ppo_impala_stack_tail_backward_bf16x3") == 3 and "ppo_impala_stack_tail_backward_bf16x3" not in calls_hi
+    assert calls_md.count("ppo_impala_stack_tail_backward_signs_bf16x3") + calls_md.count("ppo_impala_stack_tail_backward_bf16x3") == 3
+    assert calls_md.count("ppo_impala_stack_tail_forward_signs_bf16x3") == calls_md.count("ppo_impala_stack_tail_backward_signs_bf16x3") == 1
+    assert not any("bf16x3" in c for c in calls_hi)
     worst = 0.0
     for k, gh in grads["high"].items():
         scale = float(gh.abs().max())
