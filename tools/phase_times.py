@@ -1,4 +1,4 @@
-"""Synchronised wall time of the two phases of a bench iteration (bench.py's own phase split is host time: the train
+"""[PPO_PRECISION=medium] Synchronised wall time of the two phases of a bench iteration (bench.py's own phase split is host time: the train
 phase's kernels still run when its host code returns).  Usage: python tools/phase_times.py [n_steps] [iters]"""
 import os
 import sys
@@ -20,7 +20,7 @@ torch.manual_seed(1)
 np.random.seed(1)
 shape, nA = envs.get_env_spec()
 model = models.TVFModel("impala", input_dims=shape, actions=nA, device="cuda", architecture="single", hidden_units=256,
-                        head_scale=0.1, head_bias=True)
+                        head_scale=0.1, head_bias=True, precision=os.environ.get("PPO_PRECISION", "high"))
 r = rollout.Runner(model, logger.Logger(quiet=True))
 r.vec_env = envs.create_envs_classic()
 r.reset()
