@@ -382,3 +382,42 @@ def test_split_bf16_convolution_with_the_max_pool_inside_is_the_two_launches(cin
                                            hw, st), "conv + pool")
     torch.cuda.synchronize()
     assert torch.equal(p1, p2) and torch.equal(i1, i2)
+
+
+def test_split_bf16_entry_points_reject_misuse_with_a_message():
+    """Error behaviour of the new C-ABI entries: unsupported geometry, null pointers, too many problems - an error code and
+    ppo_last_error text, no launch."""
+    lib = _lib.load()
+    st = _lib.current_stream()
+    x = torch.zeros(2, 16, 42, 42, device="cuda")
+    y = torch.zeros(2, 32, 42, 42, device="cuda")
+    w = torch.zeros(32, 16, 3, 3, device="cuda")
+    pk = _pack_conv(lib, w, 0)
+    assert lib.ppo_conv3x3_bf16x3_supported(16, 32, 40, 40) == 0 and lib.ppo_conv3x3_pool_bf16x3_supported(32, 16, 42, 42) == 0
+    assert lib.ppo_conv3x3_bf16x3(x.data_ptr(), 0, pk.data_ptr(), None, y.data_ptr(), 2, 16, 32, 40, 40, st) != 0
+    assert b"no kernel" in lib.ppo_last_error()
+    assert lib.ppo_conv3x3_bf16x3(None, 0, pk.data_ptr(), None, y.data_ptr(), 2, 16, 32, 42, 42, st) != 0
+    assert b"null" in lib.ppo_last_error()
+    assert lib.ppo_conv3x3_bf16x3(x.data_ptr(), 0, pk.data_ptr() + 4, None, y.data_ptr(), 2, 16, 32, 42, 42, st) != 0  # misaligned packing
+    assert lib.ppo_conv3x3_pool_bf16x3(x.data_ptr(), 0, pk.data_ptr(), None, None, None, 2, 16, 32, 42, 42, st) != 0
+    assert lib.ppo_conv3x3_bf16x3(x.data_ptr(), 0, pk.data_ptr(), None, y.data_ptr(), 0, 16, 32, 42, 42, st) == 0  # empty batch: nothing to do
+    job = (_lib.ConvPackJob * 1)(_lib.ConvPackJob(w.data_ptr(), pk.data_ptr(), 8, 32, 0))
+    assert lib.ppo_conv3x3_pack_bf16x3_jobs(ctypes.addressof(job), 1, st) != 0 and b"16 or 32" in lib.ppo_last_error()
+    assert lib.ppo_conv3x3_pack_bf16x3_jobs(ctypes.addressof(job), 9, st) != 0
+    # weight gradients: six problems, a null workspace
+    ws = torch.zeros(int(lib.ppo_conv3x3_wgrad_workspace_bytes(16, 16)) // 4, device="cuda")
+    dy = torch.zeros(2, 16, 42, 42, device="cuda")
+    n_slabs = ctypes.c_int(0)
+    six = lambda t: (ctypes.c_void_p * 6)(*[t.data_ptr()] * 6)  # noqa: E731
+    assert lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(six(x), (ctypes.c_int * 6)(), six(dy), six(ws), ws.numel() * 4, 6, 2, 16, 16,
+                                                              42, 42, ctypes.addressof(n_slabs), st) != 0
+    one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr() if t is not None else None)  # noqa: E731
+    assert lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(one(x), (ctypes.c_int * 1)(), one(dy), one(None), ws.numel() * 4, 1, 2, 16,
+                                                              16, 42, 42, ctypes.addressof(n_slabs), st) != 0
+    assert lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(one(x), (ctypes.c_int * 1)(), one(dy), one(ws), 64, 1, 2, 16, 16, 42, 42,
+                                                              ctypes.addressof(n_slabs), st) != 0  # workspace below one slab
+    assert b"workspace" in lib.ppo_last_error()
+    # sign-map launches without their table
+    assert lib.ppo_impala_stack_tail_backward_signs_bf16x3(dy.data_ptr(), pk.data_ptr(), None, dy.data_ptr(), dy.data_ptr(), dy.data_ptr(),
+                                                           dy.data_ptr(), 2, 16, 42, 42, st) != 0
+    torch.cuda.synchronize()
