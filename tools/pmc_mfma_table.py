@@ -48,7 +48,9 @@ for key, c in counters.items():
         "share": d * len(durs[key]),
         "mfma_busy": mean["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (d * CLOCK),
         "cycles_per_mfma": mean["SQ_VALU_MFMA_BUSY_CYCLES"] / mean["SQ_INSTS_MFMA"],
-        "frac_of_peak": mean["SQ_INSTS_MFMA"] * 2048 * 64 / 64 / d / PEAK,
+        # (the opt-in split kernels issue v_mfma_f32_16x16x32_bf16: 16 384 FLOP in 16 cycles, priced against the dense bf16 peak)
+        "frac_of_peak": (mean["SQ_INSTS_MFMA"] * 16384 / d / 2516.6e12 if "bf16x3" in key[0]
+                         else mean["SQ_INSTS_MFMA"] * 2048 * 64 / 64 / d / PEAK),
         "wait_inst_any": mean["SQ_WAIT_INST_ANY"] / max(mean["SQ_WAVE_CYCLES"], 1),
         "wait_any": mean["SQ_WAIT_ANY"] / max(mean["SQ_WAVE_CYCLES"], 1),
         "valu_per_mfma": mean["SQ_INSTS_VALU"] / mean["SQ_INSTS_MFMA"],
@@ -64,7 +66,7 @@ with open(os.path.join(root, "profiles", f"{tag}_mfma_utilisation.md"), "w") as 
             "128 images); tools/pmc_mfma.sh, tools/pmc_mfma_table.py.  kernel sources "
             f"`{open(sha).read().strip() if os.path.exists(sha) else '?'}`.\n\n"
             "`MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (median duration x 2.4 GHz): the share of the launch in which "
-            "a SIMD's matrix pipe is executing; `frac` = MFMA instructions x 2048 FLOP / duration / 157.3 TFLOP/s (includes "
+            "a SIMD's matrix pipe is executing; `frac` = MFMA instructions x 2048 FLOP / duration / 157.3 TFLOP/s (`*_bf16x3_*` kernels of the opt-in precision leg: x 16 384 FLOP / 2 516.6 TFLOP/s dense bf16; includes "
             "padding work the algorithmic count in roofline_by_kernel leaves out); `wait inst` / `wait any` = share of wave "
             "cycles waiting to issue / waiting for anything; VALU (incl. MFMA) and LDS instructions per MFMA.\n\n"
             "| kernel | grid | launches | us | share of MFMA-kernel time | MFMA busy | frac | cycles / MFMA | wait inst | wait any | VALU / MFMA | LDS / MFMA |\n"
