@@ -174,3 +174,28 @@ def test_checkpoint_key_tree_matches_the_reference(tmp_path, golden_dir):
     idx = want["policy_param_names"].index("encoder.dense.weight")
     assert torch.equal(adam.state[params[idx]]["exp_avg"], r.net.exp_avg[o:o + int(np.prod(shape))].view(shape).cpu())
     assert float(adam.state[params[idx]]["step"]) == r.net._adam_step
+
+
+def test_train_main_under_precision_medium_runs_resumes_and_keeps_the_split_launches(monkeypatch, tmp_path):
+    """`train.py --precision=medium` (the reference's default value of the flag, train.py:166-178) end to end: the nets are
+    built with the split-bf16 launches, training runs and checkpoints, and a second invocation restores into a net whose
+    packed split weights are rebuilt from the restored parameters (the first forward after the restore equals a forward of a
+    fresh medium net loaded with the same state: a stale packing would differ)."""
+    from ppo_amd import models
+    out = str(tmp_path)
+    extra = ["--precision=medium", "--run_name=medium_test", "--restore=auto"]
+    r1 = run_main(monkeypatch, out, [f"--epochs={(2 * BATCH - 1) / 1e6}", *extra])
+    assert r1.net.split_bf16 and r1.net.precision == "medium" and r1.step == 2 * BATCH
+    assert torch.isfinite(r1.net.flat).all()
+    r2 = run_main(monkeypatch, out, [f"--epochs={(4 * BATCH - 1) / 1e6}", *extra])
+    assert r2.net.split_bf16 and r2.step == 4 * BATCH and torch.isfinite(r2.net.flat).all()
+    # the packed split weights follow the parameters: a fresh medium net given r2's state computes the same outputs
+    x = torch.randint(0, 256, (8, *r2.net.spec.input_dims), dtype=torch.uint8, device="cuda")
+    fresh = models.DualHeadNet("impala", r2.net.spec.input_dims, r2.net.n_actions, hidden_units=256, head_scale=0.1, head_bias=True,
+                               device="cuda", precision="medium")
+    fresh.load_state_dict({k: v.clone() for k, v in r2.net.state_dict().items()})
+    a, b = r2.net.forward(x), fresh.forward(x)
+    assert torch.equal(a["raw_policy"], b["raw_policy"]) and torch.equal(a["value"], b["value"])
+    # and the default stays exact float32
+    r3 = run_main(monkeypatch, out, [f"--epochs={(BATCH - 1) / 1e6}", "--run_name=high_test", "--precision=high"])
+    assert not r3.net.split_bf16
