@@ -120,6 +120,9 @@ SIGNATURES = {
     "ppo_conv3x3_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),
     "ppo_conv3x3_bf16x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_pool_bf16x3_supported": (_i, [_i, _i, _i, _i]),
+    "ppo_conv3x3_bf16_split_packed_bytes": (_sz, [_i, _i, _i]),
+    "ppo_conv3x3_pack_bf16_split": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ppo_conv3x3_bf16_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_pool_bf16x3": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_mlp_supported": (_i, [_i, _i, _i]),
     "ppo_mlp_forward_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

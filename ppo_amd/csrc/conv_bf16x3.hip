@@ -26,7 +26,11 @@ constexpr int kFarOutsideC = (int)0x80000000u;  // a byte offset beyond the desc
 
 constexpr int cmaxc(int a, int b) { return a > b ? a : b; }
 
-template <int CI, int CO, int H, int W, int TR, bool POOL = false>
+// NS = 2: (hi, lo) splits, three products (the opt-in precision mode).  NS = 3: (hi, mid, lo) - 8 + 8 + 8 mantissa bits, i.e.
+// the whole float32 significand - with six of the nine partial products (the dropped ones <= 2^-24 of a product): float32-
+// ACCURATE convolution on the bf16 MFMA, a measured prototype for the exact-precision path, reached
+// through ppo_conv3x3_bf16_split only.
+template <int CI, int CO, int H, int W, int TR, bool POOL = false, int NS = 2>
 struct SplitConvCfg {
     static_assert((CI == 16 || CI == 32) && (CO == 16 || CO == 32), "16 or 32 channels");
     static constexpr int NG = CI / 16, MT = CO / 16;
@@ -40,7 +44,7 @@ struct SplitConvCfg {
     static constexpr int NB = POOL ? (HO + PR - 1) / PR : (H + TR - 1) / TR;
     static constexpr int XREC = (TR + 2) * RW + 2;
     static constexpr int PLANE = XREC * 32;                   // bytes of one (group, hi | lo) plane
-    static constexpr int X_BYTES = NG * 2 * PLANE;
+    static constexpr int X_BYTES = NG * NS * PLANE;
     static constexpr int PSTR = CO + 4;                        // floats per pre-pool pixel: 36 / 20 banks apart, 16-byte accesses conflict-free
     static constexpr int PRE_BYTES = POOL ? TR * W * PSTR * 4 : 0;
     static constexpr int LDS_BYTES = X_BYTES + PRE_BYTES;
@@ -61,22 +65,26 @@ struct SplitConvArgs {
     int n_images;
 };
 
-__device__ __forceinline__ void store_split4c(unsigned char *p, int lo_off, const float (&v)[4])
+template <int NS>
+__device__ __forceinline__ void store_split4c(unsigned char *p, int plane, const float (&v)[4])
 {
-    bf16x4 hi, lo;
+    bf16x4 hi, mid, lo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         hi[r] = (__bf16)v[r];
-        lo[r] = (__bf16)(v[r] - (float)hi[r]);
+        const float r1 = v[r] - (float)hi[r];
+        mid[r] = (__bf16)r1;
+        lo[r] = (__bf16)(r1 - (float)mid[r]);
     }
     *reinterpret_cast<bf16x4 *>(p) = hi;
-    *reinterpret_cast<bf16x4 *>(p + lo_off) = lo;
+    *reinterpret_cast<bf16x4 *>(p + plane) = mid;  // NS = 2: this IS the low part (bf16 of the first remainder)
+    if (NS == 3) *reinterpret_cast<bf16x4 *>(p + 2 * plane) = lo;
 }
 
-template <int CI, int CO, int H, int W, int TR, bool POOL>
+template <int CI, int CO, int H, int W, int TR, bool POOL, int NS>
 __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitConvArgs a)
 {
-    using C = SplitConvCfg<CI, CO, H, W, TR, POOL>;
+    using C = SplitConvCfg<CI, CO, H, W, TR, POOL, NS>;
     constexpr int HW = H * W;
     extern __shared__ __align__(16) unsigned char smem_c[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
@@ -86,14 +94,13 @@ __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitCo
     for (int i = tid * 16; i < C::X_BYTES; i += kConvWaves * 64 * 16) *reinterpret_cast<uint4 *>(smem_c + i) = uint4{0, 0, 0, 0};
 
     // ---- this wave's A fragments, once
-    bf16x8 whi[C::KS], wlo[C::KS];
+    bf16x8 wsp[NS][C::KS];  // [part: 0 = hi ...][K step]
     {
-        const bf16x8 *wl = a.w + (size_t)mt * C::KS * 2 * 64 + lane;
+        const bf16x8 *wl = a.w + (size_t)mt * C::KS * NS * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-            whi[ks] = wl[(ks * 2 + 0) * 64];
-            wlo[ks] = wl[(ks * 2 + 1) * 64];
-        }
+        for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) wsp[q][ks] = wl[(ks * NS + q) * 64];
     }
     const int ch0 = mt * 16 + 4 * g;  // the four output channels of this lane
     float bias_r[4];
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitCo
             t = 2 * ks + (g >> 1) < 9 ? 2 * ks + (g >> 1) : 8;  // (the ninth pair's second tap has zero weights)
             grp = 0;
         }
-        tapoff[ks] = grp * 2 * C::PLANE + ((t / 3) * C::RW + (t % 3)) * 32 + (g & 1) * 16;
+        tapoff[ks] = grp * NS * C::PLANE + ((t / 3) * C::RW + (t % 3)) * 32 + (g & 1) * 16;
     }
     int rec0[C::TPW], pix[C::TPW];
 #pragma unroll
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitCo
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(xv[i][gi][r], a.floor, __builtin_inff());
-                    store_split4c(smem_c + gi * 2 * C::PLANE + x_rec[i], C::PLANE, v);
+                    store_split4c<NS>(smem_c + gi * NS * C::PLANE + x_rec[i], C::PLANE, v);
                 }
             }
         }
@@ -175,11 +182,20 @@ __global__ __launch_bounds__(kConvWaves * 64) void conv3x3_bf16x3_kernel(SplitCo
         for (int ks = 0; ks < C::KS; ++ks) {
 #pragma unroll
             for (int t = 0; t < C::TPW; ++t) {
-                const bf16x8 bhi = *reinterpret_cast<const bf16x8 *>(smem_c + rec0[t] + tapoff[ks]);
-                const bf16x8 blo = *reinterpret_cast<const bf16x8 *>(smem_c + rec0[t] + tapoff[ks] + C::PLANE);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[ks], bhi, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], blo, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[ks], bhi, acc[t], 0, 0, 0);
+                bf16x8 b[NS];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(smem_c + rec0[t] + tapoff[ks] + q * C::PLANE);
+                // partial products w_i x_j with i + j < NS, smallest first
+#ifndef PPO_TUNE_SPLIT3_ALL  // (timing / error aid: all nine products of the three-part form)
+#define PPO_TUNE_SPLIT3_ALL 0
+#endif
+                constexpr int TOP = (NS == 3 && PPO_TUNE_SPLIT3_ALL) ? 2 * (NS - 1) : NS - 1;
+#pragma unroll
+                for (int sum = TOP; sum >= 0; --sum)
+#pragma unroll
+                    for (int i = NS - 1; i >= 0; --i)  // (NS = 2: w_lo x_hi, w_hi x_lo, w_hi x_hi)
+                        if (i <= sum && sum - i < NS)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsp[i][ks], b[sum - i], acc[t], 0, 0, 0);
             }
         }
         const int img = item / C::NB, band = item % C::NB;
@@ -254,7 +270,7 @@ constexpr int kMaxConvPackJobs = 8;
 struct ConvPackJobs {
     const float *w[kMaxConvPackJobs];
     __bf16 *packed[kMaxConvPackJobs];
-    int cin[kMaxConvPackJobs], cout[kMaxConvPackJobs], transposed[kMaxConvPackJobs];
+    int cin[kMaxConvPackJobs], cout[kMaxConvPackJobs], transposed[kMaxConvPackJobs], ns[kMaxConvPackJobs];
     int n;
 };
 __global__ __launch_bounds__(256) void conv_pack_bf16x3_kernel(const ConvPackJobs jobs)
@@ -270,22 +286,25 @@ __global__ __launch_bounds__(256) void conv_pack_bf16x3_kernel(const ConvPackJob
     const int row = mt * 16 + (lane & 15), gq = lane >> 4;
     const int t = ci_op == 32 ? ks : 2 * ks + (gq >> 1);
     const int c0 = ci_op == 32 ? 8 * gq : 8 * (gq & 1);
-    __bf16 *hi = jobs.packed[job] + (((size_t)mt * ks_n + ks) * 2 + 0) * 64 * 8 + lane * 8;
-    __bf16 *lo = jobs.packed[job] + (((size_t)mt * ks_n + ks) * 2 + 1) * 64 * 8 + lane * 8;
+    const int ns = jobs.ns[job];
+    __bf16 *part = jobs.packed[job] + (((size_t)mt * ks_n + ks) * ns) * 64 * 8 + lane * 8;  // parts 64 * 8 elements apart
     const float *w = jobs.w[job];
     for (int j = 0; j < 8; ++j) {
         float v = 0.f;
         if (t < 9) v = tr ? w[((size_t)(c0 + j) * cin + row) * 9 + (8 - t)] : w[((size_t)row * cin + c0 + j) * 9 + t];
-        hi[j] = (__bf16)v;
-        lo[j] = (__bf16)(v - (float)hi[j]);
+        for (int q = 0; q < ns; ++q) {  // hi, then bf16 of each successive remainder
+            const __bf16 h = (__bf16)v;
+            part[q * 64 * 8 + j] = h;
+            v -= (float)h;
+        }
     }
 }
 
-template <int CI, int CO, int H, int W, int TR, bool POOL = false>
+template <int CI, int CO, int H, int W, int TR, bool POOL = false, int NS = 2>
 int launch_split_conv(const SplitConvArgs &args, hipStream_t st)
 {
-    using C = SplitConvCfg<CI, CO, H, W, TR, POOL>;
-    auto kern = conv3x3_bf16x3_kernel<CI, CO, H, W, TR, POOL>;
+    using C = SplitConvCfg<CI, CO, H, W, TR, POOL, NS>;
+    auto kern = conv3x3_bf16x3_kernel<CI, CO, H, W, TR, POOL, NS>;
     static int per_cu = 0;
     if (!per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -351,7 +370,7 @@ extern "C" int ppo_conv3x3_pack_bf16x3_jobs(const ppo_conv_pack_job *jobs, int n
         if ((q.cin != 16 && q.cin != 32) || (q.cout != 16 && q.cout != 32)) return fail(PPO_E_INVALID, "%s: 16 or 32 channels", who);
         if (!q.weight || !q.packed || !aligned(q.packed, 16)) return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
         t.w[j] = q.weight, t.packed[j] = static_cast<__bf16 *>(q.packed);
-        t.cin[j] = q.cin, t.cout[j] = q.cout, t.transposed[j] = q.transposed;
+        t.cin[j] = q.cin, t.cout[j] = q.cout, t.transposed[j] = q.transposed, t.ns[j] = 2;
     }
     hipLaunchKernelGGL(conv_pack_bf16x3_kernel, dim3((2 * 9 * 64 + 255) / 256, n_jobs), dim3(256), 0, as_stream(stream), t);
     return check_launch("conv_pack_bf16x3_kernel");
@@ -402,4 +421,44 @@ extern "C" int ppo_conv3x3_pool_bf16x3(const float *in, int relu_in, const void 
     PPO_SPLIT_CONV_POOL_GEOMETRIES(X)
 #undef X
     return fail(PPO_E_INVALID, "%s: no kernel for %d -> %d channels at %dx%d", who, cin, cout, h, w);
+}
+
+// ---- prototype: n_split = 3 is the float32-accurate form (six bf16 MFMAs per product block); n_split = 2 the shipped one
+extern "C" size_t ppo_conv3x3_bf16_split_packed_bytes(int cin, int cout, int n_split)
+{
+    return ppo_conv3x3_bf16x3_packed_bytes(cin, cout) / 2 * (size_t)n_split;
+}
+
+extern "C" int ppo_conv3x3_pack_bf16_split(const float *weight, void *packed, int cin, int cout, int transposed, int n_split,
+                                           void *stream)
+{
+    using namespace ppo;
+    const char *who = "ppo_conv3x3_pack_bf16_split";
+    if (n_split != 2 && n_split != 3) return fail(PPO_E_INVALID, "%s: 2 or 3 parts", who);
+    if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return fail(PPO_E_INVALID, "%s: 16 or 32 channels", who);
+    if (!weight || !packed || !aligned(packed, 16)) return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
+    ConvPackJobs t{};
+    t.n = 1, t.w[0] = weight, t.packed[0] = static_cast<__bf16 *>(packed);
+    t.cin[0] = cin, t.cout[0] = cout, t.transposed[0] = transposed, t.ns[0] = n_split;
+    hipLaunchKernelGGL(conv_pack_bf16x3_kernel, dim3((2 * 9 * 64 + 255) / 256, 1), dim3(256), 0, as_stream(stream), t);
+    return check_launch("conv_pack_bf16x3_kernel");
+}
+
+extern "C" int ppo_conv3x3_bf16_split(const float *in, int relu_in, const void *packed, const float *bias, float *out, int n, int cin,
+                                      int cout, int h, int w, int n_split, void *stream)
+{
+    using namespace ppo;
+    const char *who = "ppo_conv3x3_bf16_split";
+    if (n_split == 2) return ppo_conv3x3_bf16x3(in, relu_in, packed, bias, out, n, cin, cout, h, w, stream);
+    if (n_split != 3) return fail(PPO_E_INVALID, "%s: 2 or 3 parts", who);
+    if (n < 0) return fail(PPO_E_INVALID, "%s: negative batch", who);
+    if (n == 0) return PPO_OK;
+    if (!in || !packed || !out || !aligned(packed, 16)) return fail(PPO_E_INVALID, "%s: null or misaligned pointer", who);
+    if ((size_t)n * (cin > cout ? cin : cout) * h * w * sizeof(float) >= kBufferBytes)
+        return fail(PPO_E_INVALID, "%s: tensor beyond the 2 GB a buffer descriptor spans", who);
+    SplitConvArgs args{in, static_cast<const bf16x8 *>(packed), bias, out, nullptr, relu_in ? 0.f : -__builtin_inff(), n};
+    if (cin == 16 && cout == 32 && h == 42 && w == 42) return launch_split_conv<16, 32, 42, 42, 7, false, 3>(args, as_stream(stream));
+    if (cin == 32 && cout == 16 && h == 42 && w == 42) return launch_split_conv<32, 16, 42, 42, 7, false, 3>(args, as_stream(stream));
+    if (cin == 32 && cout == 32 && h == 21 && w == 21) return launch_split_conv<32, 32, 21, 21, 7, false, 3>(args, as_stream(stream));
+    return fail(PPO_E_INVALID, "%s: no three-part kernel for %d -> %d channels at %dx%d", who, cin, cout, h, w);
 }
