@@ -120,6 +120,7 @@ SIGNATURES = {
     "ppo_conv3x3_pack_bf16x3_jobs": (_i, [_vp, _i, _vp]),
     "ppo_conv3x3_bf16x3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_pool_bf16x3_supported": (_i, [_i, _i, _i, _i]),
+    "ppo_conv3x3_backward_weight_slabs_batch_bf16_split": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ppo_conv3x3_bf16_split_packed_bytes": (_sz, [_i, _i, _i]),
     "ppo_conv3x3_pack_bf16_split": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_bf16_split": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

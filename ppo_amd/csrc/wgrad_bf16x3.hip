@@ -58,6 +58,15 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 #ifndef PPO_TUNE_W3_MAP
 #define PPO_TUNE_W3_MAP 1
 #endif
+#ifndef PPO_TUNE_W3X3_TR42  // band heights of the three-part form (LDS is half as large again per band row)
+#define PPO_TUNE_W3X3_TR42 7
+#endif
+#ifndef PPO_TUNE_W3X3_TR42B
+#define PPO_TUNE_W3X3_TR42B 5
+#endif
+#ifndef PPO_TUNE_W3X3_TR21
+#define PPO_TUNE_W3X3_TR21 5
+#endif
 #ifndef PPO_TUNE_W3_TR21   // band heights of 32 -> 32 at 21x21 and 16 -> 32 at 42x42
 #define PPO_TUNE_W3_TR21 7
 #endif
@@ -65,7 +74,9 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 #define PPO_TUNE_W3_TR42B 7
 #endif
 
-template <int CIN, int COUT, int H, int W, int TR>
+// NS = 2: (hi, lo) parts, three products (`--precision=medium`).  NS = 3: (hi, mid, lo) = the whole float32 significand, six of
+// the nine partial products (float32-accurate: profiles/r04_bf16_three_part_prototype.md; `--precision=high_bf16x6`).
+template <int CIN, int COUT, int H, int W, int TR, int NS = 2>
 struct SplitWgradCfg {
     static_assert(CIN % 16 == 0 && COUT % 16 == 0 && CIN <= 32 && COUT <= 32, "16 or 32 channels");
     static constexpr int NGI = CIN / 16, MT = COUT / 16;
@@ -78,7 +89,7 @@ struct SplitWgradCfg {
     static constexpr int KG = kSplitWaves / OWN;              // K groups
     static constexpr int SPG = (STEPS + KG - 1) / KG;         // steps per K group
     static constexpr int X_IMG = XREC * kRecBytes, D_IMG = DREC * kRecBytes;
-    static constexpr int X_BYTES = NGI * 2 * X_IMG, D_BYTES = MT * 2 * D_IMG;
+    static constexpr int X_BYTES = NGI * NS * X_IMG, D_BYTES = MT * NS * D_IMG;
     static constexpr int JP = ((9 * CIN + 1) + 15) / 16 * 16; // slab row (conv3x3_wgrad.hip): j = tap * CIN + i, then db
     static constexpr int SLAB_BYTES = COUT * JP * 4 + kSplitWaves * COUT * 4;
     static constexpr int LDS_BYTES = cmax(X_BYTES + D_BYTES, SLAB_BYTES);
@@ -95,23 +106,27 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p)
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// four float32 -> (hi, lo) bf16 quads at p and p + lo_off
-__device__ __forceinline__ void store_split4(unsigned char *p, int lo_off, const float (&v)[4])
+// four float32 -> NS bf16 quads (hi, then bf16 of each successive remainder) at p, p + plane, ...
+template <int NS>
+__device__ __forceinline__ void store_split4(unsigned char *p, int plane, const float (&v)[4])
 {
-    bf16x4 hi, lo;
+    bf16x4 hi, mid, lo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         hi[r] = (__bf16)v[r];
-        lo[r] = (__bf16)(v[r] - (float)hi[r]);
+        const float r1 = v[r] - (float)hi[r];
+        mid[r] = (__bf16)r1;
+        lo[r] = (__bf16)(r1 - (float)mid[r]);
     }
     *reinterpret_cast<bf16x4 *>(p) = hi;
-    *reinterpret_cast<bf16x4 *>(p + lo_off) = lo;
+    *reinterpret_cast<bf16x4 *>(p + plane) = mid;
+    if (NS == 3) *reinterpret_cast<bf16x4 *>(p + 2 * plane) = lo;
 }
 
-template <int CIN, int COUT, int H, int W, int TR>
+template <int CIN, int COUT, int H, int W, int TR, int NS>
 __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(SplitWgradBatch batch, int n_images)
 {
-    using C = SplitWgradCfg<CIN, COUT, H, W, TR>;
+    using C = SplitWgradCfg<CIN, COUT, H, W, TR, NS>;
     constexpr int HW = H * W;
     extern __shared__ __align__(16) unsigned char smem_w[];
     unsigned char *const s_x = smem_w;               // [NGI][hi, lo][XREC] records
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(xv[i][gi][r], floor, __builtin_inff());
-                    store_split4(s_x + gi * 2 * C::X_IMG + x_rec[i], C::X_IMG, v);
+                    store_split4<NS>(s_x + gi * NS * C::X_IMG + x_rec[i], C::X_IMG, v);
                 }
             }
         }
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
                 for (int m = 0; m < C::MT; ++m) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bsum[m][r] += dv[i][m][r];
-                    store_split4(s_d + m * 2 * C::D_IMG + d_rec[i], C::D_IMG, dv[i][m]);
+                    store_split4<NS>(s_d + m * NS * C::D_IMG + d_rec[i], C::D_IMG, dv[i][m]);
                 }
             }
         }
@@ -227,26 +242,29 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
         __syncthreads();  // the band is complete
         if (item + (int)gridDim.x < n_items) issue(item + gridDim.x);
         // ---- K loop: steps of this wave's K group, all nine taps of its input-channel group, every output tile
-        const unsigned char *xs = s_x + own * 2 * C::X_IMG + blk + s_begin * 32 * kRecBytes;
+        const unsigned char *xs = s_x + own * NS * C::X_IMG + blk + s_begin * 32 * kRecBytes;
         const unsigned char *ds = s_d + blk + s_begin * 32 * kRecBytes;
 #pragma unroll 1
         for (int s = s_begin; s < ((PPO_TUNE_W3_SKIP & 4) ? s_begin : s_end); ++s) {
-            bf16x8 ahi[C::MT], alo[C::MT];
+            bf16x8 ap[NS][C::MT];  // dy parts: 0 = hi
 #pragma unroll
-            for (int m = 0; m < C::MT; ++m) {
-                ahi[m] = tr_read2(ds + m * 2 * C::D_IMG);
-                alo[m] = tr_read2(ds + m * 2 * C::D_IMG + C::D_IMG);
-            }
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int q = 0; q < NS; ++q) ap[q][m] = tr_read2(ds + (m * NS + q) * C::D_IMG);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int toff = ((t / 3) * C::RW + (t % 3)) * kRecBytes;  // dy record d <-> x record d + ky RW + kx (guard + halo included)
-                const bf16x8 bhi = tr_read2(xs + toff);
-                const bf16x8 blo = tr_read2(xs + toff + C::X_IMG);
+                bf16x8 bp[NS];
+#pragma unroll
+                for (int q = 0; q < NS; ++q) bp[q] = tr_read2(xs + toff + q * C::X_IMG);
 #pragma unroll
                 for (int m = 0; m < C::MT; ++m) {
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[m], bhi, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[m], blo, acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[m], bhi, acc[m][t], 0, 0, 0);
+                    // partial products a_i b_j with i + j < NS, smallest first (NS = 2: lo hi, hi lo, hi hi)
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = sum; i >= 0; --i)
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i][m], bp[sum - i], acc[m][t], 0, 0, 0);
                 }
             }
             xs += 32 * kRecBytes;
@@ -303,11 +321,11 @@ __global__ __launch_bounds__(kSplitWaves * 64) void conv3x3_wgrad_bf16x3_kernel(
     for (int i = tid; i < COUT * C::JP / 4; i += kSplitWaves * 64) out[i] = reinterpret_cast<const float4 *>(s_slab)[i];
 }
 
-template <int CIN, int COUT, int H, int W, int TR>
+template <int CIN, int COUT, int H, int W, int TR, int NS = 2>
 int launch_split_wgrad(const SplitWgradBatch &b, int count, int n_images, size_t workspace_bytes, int *n_slabs, hipStream_t st)
 {
-    using C = SplitWgradCfg<CIN, COUT, H, W, TR>;
-    auto kern = conv3x3_wgrad_bf16x3_kernel<CIN, COUT, H, W, TR>;
+    using C = SplitWgradCfg<CIN, COUT, H, W, TR, NS>;
+    auto kern = conv3x3_wgrad_bf16x3_kernel<CIN, COUT, H, W, TR, NS>;
     static int per_cu = 0;
     if (!per_cu) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -358,12 +376,11 @@ extern "C" int ppo_conv3x3_backward_weight_bf16x3_supported(int cin, int cout, i
     return 0;
 }
 
-extern "C" int ppo_conv3x3_backward_weight_slabs_batch_bf16x3(const float *const *ins, const int *relu, const float *const *dys,
-                                                              void *const *workspaces, size_t workspace_bytes, int count, int n,
-                                                              int cin, int cout, int h, int w, int *n_slabs, void *stream)
+static int split_wgrad_entry(const char *who, int n_split, const float *const *ins, const int *relu, const float *const *dys,
+                             void *const *workspaces, size_t workspace_bytes, int count, int n, int cin, int cout, int h, int w,
+                             int *n_slabs, void *stream)
 {
     using namespace ppo;
-    const char *who = "ppo_conv3x3_backward_weight_slabs_batch_bf16x3";
     if (count < 1 || count > kSplitWgradBatch) return fail(PPO_E_INVALID, "%s: 1 .. %d problems per launch", who, kSplitWgradBatch);
     if (!ins || !relu || !dys || !workspaces || !n_slabs) return fail(PPO_E_INVALID, "%s: null pointer", who);
     if (n <= 0) return fail(PPO_E_INVALID, "%s: empty batch", who);
@@ -375,10 +392,40 @@ extern "C" int ppo_conv3x3_backward_weight_slabs_batch_bf16x3(const float *const
         b.in[i] = ins[i], b.dy[i] = dys[i], b.partial[i] = static_cast<float *>(workspaces[i]);
         b.floor[i] = relu[i] ? 0.f : -__builtin_inff();
     }
+    if (n_split == 3) {  // the Atari-shaped net's layers only
+#define X3(CI, CO, HH, WW, TR)                         \
+    if (cin == CI && cout == CO && h == HH && w == WW) \
+        return launch_split_wgrad<CI, CO, HH, WW, TR, 3>(b, count, n, workspace_bytes, n_slabs, as_stream(stream));
+        X3(16, 16, 42, 42, PPO_TUNE_W3X3_TR42)
+        X3(16, 32, 42, 42, PPO_TUNE_W3X3_TR42B)
+        X3(32, 32, 21, 21, PPO_TUNE_W3X3_TR21)
+        X3(32, 32, 11, 11, 11)
+#undef X3
+        return fail(PPO_E_INVALID, "%s: no three-part kernel for %d -> %d channels at %dx%d", who, cin, cout, h, w);
+    }
 #define X(CI, CO, HH, WW, TR)                                 \
     if (cin == CI && cout == CO && h == HH && w == WW)        \
         return launch_split_wgrad<CI, CO, HH, WW, TR>(b, count, n, workspace_bytes, n_slabs, as_stream(stream));
     PPO_SPLIT_WGRAD_GEOMETRIES(X)
 #undef X
     return fail(PPO_E_INVALID, "%s: no kernel for %d -> %d channels at %dx%d", who, cin, cout, h, w);
+}
+
+extern "C" int ppo_conv3x3_backward_weight_slabs_batch_bf16x3(const float *const *ins, const int *relu, const float *const *dys,
+                                                              void *const *workspaces, size_t workspace_bytes, int count, int n,
+                                                              int cin, int cout, int h, int w, int *n_slabs, void *stream)
+{
+    return split_wgrad_entry("ppo_conv3x3_backward_weight_slabs_batch_bf16x3", 2, ins, relu, dys, workspaces, workspace_bytes, count, n,
+                             cin, cout, h, w, n_slabs, stream);
+}
+
+/* n_split = 3: the float32-accurate three-part form (six products); n_split = 2 is the entry point above */
+extern "C" int ppo_conv3x3_backward_weight_slabs_batch_bf16_split(const float *const *ins, const int *relu, const float *const *dys,
+                                                                  void *const *workspaces, size_t workspace_bytes, int count, int n,
+                                                                  int cin, int cout, int h, int w, int n_split, int *n_slabs,
+                                                                  void *stream)
+{
+    if (n_split != 2 && n_split != 3) return ppo::fail(PPO_E_INVALID, "ppo_conv3x3_backward_weight_slabs_batch_bf16_split: 2 or 3 parts");
+    return split_wgrad_entry("ppo_conv3x3_backward_weight_slabs_batch_bf16_split", n_split, ins, relu, dys, workspaces, workspace_bytes,
+                             count, n, cin, cout, h, w, n_slabs, stream);
 }

@@ -459,3 +459,50 @@ def test_three_part_split_convolution_is_float32_accurate(cin, cout, hw):
     print(f"{cin}->{cout} {hw}x{hw}: max error / max|ref|  exact f32 {e32}   three parts {errs[3]:.2e}   two parts {errs[2]:.2e}")
     assert errs[3] <= 1e-6 and errs[3] < errs[2] / 4
     assert e32 is None or (e32 <= 1e-6 and errs[3] <= 1.5 * e32)  # no worse than the float32 MFMA kernel's own rounding
+
+
+@pytest.mark.parametrize("cin,cout,hw,k", [(16, 16, 42, 4), (16, 32, 42, 1), (32, 32, 21, 5), (32, 32, 11, 4)])
+def test_three_part_split_weight_gradients_are_float32_accurate(cin, cout, hw, k):
+    """The three-part form of the weight-gradient launch (six products): against float64 no worse than the exact float32 kernel
+    on the same data (both printed), and well below the two-part form."""
+    import torch.nn.functional as F
+    lib = _lib.load()
+    st = _lib.current_stream()
+    g = torch.Generator().manual_seed(cin + cout + hw + k)
+    n = 64
+    xs = [(torch.randn(n, cin, hw, hw, generator=g) * 1.7).to("cuda") for _ in range(k)]
+    dys = [(torch.randn(n, cout, hw, hw, generator=g) * 0.3).to("cuda") for _ in range(k)]
+    mode = 1 if cin == cout else 0
+    ws_bytes = lib.ppo_conv3x3_wgrad_workspace_bytes(cin, cout)
+    res = {}
+    for name in ("f32", 2, 3):
+        wss = [torch.zeros(ws_bytes // 4, device="cuda") for _ in range(k)]
+        ins = (ctypes.c_void_p * k)(*[t.data_ptr() for t in xs])
+        relu = (ctypes.c_int * k)(*([mode] * k))
+        dyp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dys])
+        wsp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in wss])
+        n_slabs = ctypes.c_int(0)
+        if name == "f32":
+            fn = lib.ppo_conv3x3_backward_weight_slabs_batch_mixed_f32 if k > 4 else None
+            if fn is not None:
+                rc = fn(ins, relu, dyp, wsp, ws_bytes, k, n, cin, cout, hw, hw, ctypes.addressof(n_slabs), st)
+            else:
+                rc = lib.ppo_conv3x3_backward_weight_slabs_batch_f32(ins, mode, dyp, wsp, ws_bytes, k, n, cin, cout, hw, hw,
+                                                                     ctypes.addressof(n_slabs), st)
+        else:
+            rc = lib.ppo_conv3x3_backward_weight_slabs_batch_bf16_split(ins, relu, dyp, wsp, ws_bytes, k, n, cin, cout, hw, hw, name,
+                                                                        ctypes.addressof(n_slabs), st)
+        _lib.check(rc, f"wgrad {name}")
+        outs = [(torch.empty(cout, cin, 3, 3, device="cuda"), torch.empty(cout, device="cuda")) for _ in range(k)]
+        jobs = [_lib.WgradJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr(), n_slabs.value, cin, cout, 0) for ws, (dw, db) in zip(wss, outs)]
+        table = (_lib.WgradJob * k)(*jobs)
+        _lib.check(lib.ppo_conv3x3_wgrad_reduce_f32(ctypes.addressof(table), k, st), "reduce")
+        worst = 0.0
+        for x, dy, (dw, _db) in zip(xs, dys, outs):
+            xin = (F.relu(x) if mode else x).double().cpu()
+            w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+            rw, = torch.autograd.grad(F.conv2d(xin, w, None, padding=1), (w,), dy.double().cpu())
+            worst = max(worst, float((dw.double().cpu() - rw).abs().max()) / float(rw.abs().max()))
+        res[name] = worst
+    print(f"{k} x {cin}->{cout} {hw}x{hw}: max error / max|dW|  exact f32 {res['f32']:.2e}   three parts {res[3]:.2e}   two parts {res[2]:.2e}")
+    assert res[3] <= 2e-6 and res[3] <= 2.0 * res["f32"] and res[3] < res[2] / 4

@@ -29,8 +29,9 @@ for cin, cout, hw, k in [(16, 16, 42, 4), (16, 32, 42, 1), (32, 32, 21, 5), (32,
     for name in ("f32", "bf16x3"):
         def run():
             if name == "bf16x3":
-                rc = lib.ppo_conv3x3_backward_weight_slabs_batch_bf16x3(ins, relu, dyp, wsp, ws_bytes, k, n, cin, cout, hw, hw,
-                                                                        ctypes.addressof(n_slabs), st)
+                rc = lib.ppo_conv3x3_backward_weight_slabs_batch_bf16_split(ins, relu, dyp, wsp, ws_bytes, k, n, cin, cout, hw, hw,
+                                                                            int(os.environ.get("PPO_N_SPLIT", "2")),
+                                                                            ctypes.addressof(n_slabs), st)
             elif k > 4:
                 rc = lib.ppo_conv3x3_backward_weight_slabs_batch_mixed_f32(ins, relu, dyp, wsp, ws_bytes, k, n, cin, cout, hw, hw,
                                                                            ctypes.addressof(n_slabs), st)
