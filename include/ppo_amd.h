@@ -723,6 +723,8 @@ int ppo_conv3x3_pool_bf16x3(const float *in, int relu_in, const void *packed, co
  * operand - (hi, mid, lo), 8 + 8 + 8 mantissa bits = the whole float32 significand - and six of the nine partial products
  * (the dropped ones <= 2^-24 of a product): float32-ACCURATE arithmetic on the bf16 MFMA, not bit-identical to the float32
  * MFMA.  n_split = 2 is ppo_conv3x3_bf16x3.  Three-part geometries: 16->32 and 32->16 at 42x42, 32->32 at 21x21. */
+/* ... and the weight-gradient launch with n_split parts per operand (2 = ppo_conv3x3_backward_weight_slabs_batch_bf16x3; 3: the
+ * Atari-shaped net's four geometries) */
 int ppo_conv3x3_backward_weight_slabs_batch_bf16_split(const float *const *ins, const int *relu, const float *const *dys,
                                                        void *const *workspaces, size_t workspace_bytes, int count, int n, int cin,
                                                        int cout, int h, int w, int n_split, int *n_slabs, void *stream);
