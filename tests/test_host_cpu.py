@@ -361,3 +361,37 @@ def test_affinity_plan_on_a_fake_two_socket_node(tmp_path):
     assert affinity.plan(1, 4, range(16), r, env={}) == [4, 5, 6, 7]
     assert affinity.plan(1, 2, range(8), str(tmp_path / "nothing"), env={}) == [4, 5, 6, 7]
     assert affinity.plan(0, 1, [3], r, env={}) is None
+
+
+def test_affinity_release_hands_every_thread_its_mask_back():
+    """What bench.py does around its CPU-baseline leg: threads started while the rank was pinned inherited the narrow
+    mask; release() widens all of them again (in a child process, so that the test runner's own mask is not touched)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, threading, time
+from ppo_amd import affinity
+before = os.sched_getaffinity(0)
+if len(before) < 2:
+    print("SKIP"); raise SystemExit(0)
+assert affinity.release() is False          # nothing was pinned yet
+narrow = sorted(before)[:1]
+os.sched_setaffinity(0, narrow)
+affinity._unpinned_mask = set(before)        # (what pin_rank records when it narrows the mask)
+stop = threading.Event()
+seen = {}
+def worker():
+    seen["start"] = os.sched_getaffinity(0)
+    stop.wait()
+    seen["end"] = os.sched_getaffinity(0)
+t = threading.Thread(target=worker); t.start()
+time.sleep(0.05)
+assert affinity.release() is True
+stop.set(); t.join()
+assert seen["start"] == set(narrow) and seen["end"] == before and os.sched_getaffinity(0) == before
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() in ("OK", "SKIP")
