@@ -74,6 +74,7 @@ SIGNATURES = {
     "ppo_conv3x3_backward_data_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_pool_forward_packed_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_pool_forward_packed_indexed_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ppo_conv1_pool_form": (_i, [_i]),
     "ppo_conv3x3_block_supported": (_i, [_i, _i, _i]),
     "ppo_conv3x3_block_forward_packed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ppo_conv3x3_backward_weight_slabs_f32": (_i, [_vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _vp]),

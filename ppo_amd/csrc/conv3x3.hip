@@ -33,6 +33,12 @@
 #include "mfma.h"
 
 namespace ppo {
+
+// conv1_pool.hip: the first layer on uint8 observations, pooled out of the MFMA accumulators
+bool conv1_pool_supported(int cin, int cout, int h, int w, bool train);
+int conv1_pool_forward(const void *in, const int32_t *in_index, const float *w, bool packed, const float *bias, float *out,
+                       uint8_t *argmax, int n, int cin, int h, int w_, hipStream_t st);
+
 namespace {
 
 // Waves per workgroup (NW) is a per-geometry choice: 8 for the 16-channel layers (several workgroups fit a
@@ -960,6 +966,10 @@ int dispatch_conv_pool(int cin, int cout, int h, int w_, const void *in, const f
             return launch_conv_pool<CI, CO, HH, WW, PR, MT, NW, IN_MODE>(in, w, bias, out, argmax, n, st);  \
     }
     constexpr bool FLOAT = IN_MODE == IN_NONE;
+    if constexpr (IN_MODE == IN_U8) {
+        if (conv1_pool_supported(cin, cout, h, w_, argmax != nullptr))
+            return conv1_pool_forward(in, t_in_index, w, t_weights_packed != 0, bias, out, argmax, n, cin, h, w_, st);
+    }
 #ifndef PPO_CP_PR84  // 84x84 first layer: pooled rows per item / pixel tiles per wave group
 #define PPO_CP_PR84 3   // 7 rows x 84 = 37 tiles -> 8 groups of 5; 51 KB of LDS: three workgroups per CU
 #define PPO_CP_MT84 5

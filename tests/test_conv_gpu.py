@@ -113,12 +113,23 @@ def test_unsupported_geometry_is_an_error():
                                             (16, 32, 42, False), (16, 32, 32, False), (32, 32, 21, False),
                                             (32, 32, 16, False)])
 @pytest.mark.parametrize("n", [1, 5, 130])
-def test_fused_conv_pool_equals_conv_then_pool_bitwise(cin, cout, hw, u8, n):
+@pytest.mark.parametrize("form", [-1, 0, 1])  # ppo_conv1_pool_form: by measurement / from the accumulators / LDS form
+def test_fused_conv_pool_equals_conv_then_pool_bitwise(cin, cout, hw, u8, n, form):
     """ppo_conv3x3_pool_forward_f32 (stack-first conv + max-pool, the pre-pool map stays in LDS) must give
     exactly what the two separate entry points give — same MFMA accumulation order, same pooling rule
     (first maximum in row-major window order, padding excluded) — and match torch's conv2d + max_pool2d."""
     lib = _lib.load()
     dev = torch.device("cuda")
+    if form != -1 and not u8:
+        pytest.skip("the form switch concerns the uint8 first layer")
+    before = lib.ppo_conv1_pool_form(form)
+    try:
+        _fused_conv_pool_case(lib, dev, cin, cout, hw, u8, n)
+    finally:
+        lib.ppo_conv1_pool_form(before)
+
+
+def _fused_conv_pool_case(lib, dev, cin, cout, hw, u8, n):
     g = torch.Generator(device=dev).manual_seed(cin * 1000 + hw + n)
     if u8:
         x = torch.randint(0, 256, (n, cin, hw, hw), generator=g, device=dev, dtype=torch.uint8)
@@ -197,6 +208,67 @@ def test_packed_weights_give_the_raw_weight_results_bitwise(cin, cout, hw):
         _lib.check(lib.ppo_conv3x3_pool_forward_packed_f32(_p(x), 0, _p(pf), _p(b), _p(p2), _p(i2), n, cin, cout, hw, hw,
                                                            _lib.current_stream()), "pool packed")
         assert torch.equal(p1, p2) and torch.equal(i1, i2)
+
+
+@pytest.mark.parametrize("cin,hw", [(4, 84), (3, 64)])  # 64x64 has no such kernel: the same cases through the LDS form
+@pytest.mark.parametrize("n", [2, 100, 200, 261])  # the three strip lengths of conv1_pool.hip's launch
+def test_first_layer_pooled_from_the_accumulators_special_cases(cin, hw, n):
+    """conv1_pool.hip (uint8 observations, pooled out of the MFMA accumulators with DPP row shifts): the windows its
+    fast path hands to the reference scan - black regions under a zero bias (a zero maximum, whose SIGN is that of the
+    first zero in the window: compared as bit patterns), a channel with a NaN weight, a channel at +inf - and the
+    packed-weight + minibatch-index form, all against the separate convolution and max-pool launches."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    before = lib.ppo_conv1_pool_form(0)  # this kernel for the training form and the 64x64 maps too
+    try:
+        _first_layer_special_cases(lib, dev, cin, hw, n)
+    finally:
+        lib.ppo_conv1_pool_form(before)
+
+
+def _first_layer_special_cases(lib, dev, cin, hw, n):
+    import ctypes
+    g = torch.Generator(device=dev).manual_seed(cin * 7 + hw + n)
+    x = torch.randint(0, 256, (n, cin, hw, hw), generator=g, device=dev, dtype=torch.uint8)
+    x[:, :, : hw // 3] = 0                      # a black band: rows of exact zeros (of either sign) in every channel
+    x[0] = 0
+    x[1 % n, :, :, hw // 2:] = 0
+    w = (torch.randn(16, cin, 3, 3, generator=g, device=dev) * 4).round() / 16
+    b = (torch.randn(16, generator=g, device=dev) * 4).round() / 8
+    b[:6] = 0.0
+    b[2] = -0.0
+    w[5, 0, 1, 1] = float("nan")
+    w[7, 0, 0, 2] = float("inf")
+    ho = hw // 2
+    c = conv_fwd(x, w, b, None, _lib.PPO_IN_U8)
+    p_ref = torch.empty(n, 16, ho, ho, device=dev)
+    i_ref = torch.empty(n, 16, ho, ho, device=dev, dtype=torch.uint8)
+    _lib.check(lib.ppo_maxpool3x3s2_forward_f32(_p(c), _p(p_ref), _p(i_ref), n, 16, hw, hw, _lib.current_stream()), "pool")
+    p = torch.full((n, 16, ho, ho), 3.0, device=dev)
+    i = torch.full((n, 16, ho, ho), 255, device=dev, dtype=torch.uint8)
+    _lib.check(lib.ppo_conv3x3_pool_forward_f32(_p(x), 2, _p(w), _p(b), _p(p), _p(i), n, cin, 16, hw, hw,
+                                                _lib.current_stream()), "ppo_conv3x3_pool_forward_f32")
+    torch.cuda.synchronize()
+    finite = torch.isfinite(p_ref)
+    assert torch.equal(torch.isnan(p), torch.isnan(p_ref))
+    assert torch.equal(p.view(torch.int32)[~torch.isnan(p_ref)], p_ref.view(torch.int32)[~torch.isnan(p_ref)])
+    assert torch.equal(i, i_ref)
+    assert finite.any() and (~finite).any() and (p_ref == 0).any()
+    # inference form, packed weights, images read through a permutation
+    pf = torch.zeros((lib.ppo_conv3x3_packed_floats(cin, 16, 0),), device=dev)
+    jobs = (_lib.PackJob * 1)(_lib.PackJob(_p(w), _p(pf), cin, 16, 0))
+    _lib.check(lib.ppo_conv3x3_pack_weights_f32(ctypes.addressof(jobs), 1, _lib.current_stream()), "pack")
+    perm = torch.randperm(n, generator=g, device=dev).to(torch.int32)
+    for amx in (None, i):
+        p2 = torch.full_like(p, 3.0)
+        _lib.check(lib.ppo_conv3x3_pool_forward_packed_indexed_f32(_p(x), _p(perm), 2, _p(pf), _p(b), _p(p2), _p(amx), n, cin, 16,
+                                                                   hw, hw, _lib.current_stream()), "packed indexed")
+        want = p_ref[perm.long()]
+        ok = ~torch.isnan(want)
+        assert torch.equal(torch.isnan(p2), ~ok) and torch.equal(p2.view(torch.int32)[ok], want.view(torch.int32)[ok])
+        if amx is not None:
+            assert torch.equal(i, i_ref[perm.long()])
 
 
 @pytest.mark.parametrize("cin,hw", [(4, 84), (3, 64)])
