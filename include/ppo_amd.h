@@ -161,10 +161,10 @@ int ppo_conv3x3_backward_weight_slabs_pooled_indexed_f32(const void *in, const i
                                                          const uint8_t *argmax, void *workspace, size_t workspace_bytes,
                                                          int n, int cin, int cout, int h, int w, int *n_slabs, void *stream);
 /* Which kernel the uint8 first-layer launches of ppo_conv3x3_pool_forward_*f32 take (rl/impala.py:96,104-105): the LDS
- * form (conv3x3.hip) or the form that pools out of the MFMA accumulators (conv1_pool.hip).  Both are bit-identical, so this
- * selects speed, never results: form -1 = by measurement (the default: 84x84 inference launches pool from the
- * accumulators), 0 = accumulators wherever the geometry is supported, 1 = LDS form everywhere.  Returns the previous
- * setting; process-wide, for A/B timing and the tests. */
+ * form (conv3x3.hip) or the form that pools out of the MFMA accumulators (conv1_pool.hip, 4 x 84 x 84 observations).  Both are
+ * bit-identical, so this selects speed, never results: form 0 = from the accumulators wherever that kernel exists, 1 = the LDS
+ * form everywhere, -1 = the measured default (today the LDS form: faster inside the pipelined rollout).
+ * Returns the previous setting; process-wide, for A/B timing and the tests. */
 int ppo_conv1_pool_form(int form);
 
 /*

@@ -338,18 +338,20 @@ int launch_conv1(const void *in, const int32_t *in_index, const float *w, const 
 
 }  // namespace
 
-// Whether a first-layer launch takes this form.  Measured on one MI355X (tools/conv1_speed.py, profiles/r04p_conv1_pool.md):
-// 84x84 inference launches 43.1 -> 35.5 us at 256 images and 23.5 -> 20.1 us at 128; the training form (argmax) 46.2
-// against the LDS form's 45.4 us, so that one stays on conv3x3_pool_kernel unless ppo_conv1_pool_form(0) /
-// PPO_AMD_CONV1_LDS=0 asks for this form wherever it exists (1: the LDS form everywhere).  Both are bit-identical: a
-// speed switch, not a result switch.  The 64x64 (Procgen) maps have no instance: 32 pooled columns are 4.6 tiles.
+// Whether a first-layer launch takes this form: only when asked (ppo_conv1_pool_form(0) / PPO_AMD_CONV1_LDS=0).  Measured on one
+// MI355X (profiles/r04p_conv1_pool.md): back-to-back launches on a hot input are faster in the inference form (84x84: 44.0 ->
+// 35.4 us at 256 images, 22.9 -> 20.4 us at 128; training form 45.5 vs 46.4 us), but INSIDE the pipelined rollout, where the
+// observations have just been uploaded and the other env group's kernels share the chip, an env step is slower with it
+// (0.4933 vs 0.4727 ms, interleaved A/B tools/rollout_ab.py PPO_AB=conv1): a strip requests its input only two rows ahead
+// and pays the cold-memory latency row by row, where the LDS form has a whole band in flight.  So the default is the LDS
+// form everywhere (-1 and 1 are the same today); both kernels are bit-identical: a speed switch, not a result switch.
 static int g_form = getenv("PPO_AMD_CONV1_LDS") ? atoi(getenv("PPO_AMD_CONV1_LDS")) : -1;
 
 bool conv1_pool_supported(int cin, int cout, int h, int w, bool train)
 {
     const bool can = cin == 4 && cout == 16 && h == 84 && w == 84;  // the Atari first layer (rl/atari.py: 4 stacked 84x84 frames)
-    if (g_form >= 0) return can && g_form == 0;
-    return can && !train;
+    (void)train;
+    return can && g_form == 0;
 }
 
 int conv1_pool_forward(const void *in, const int32_t *in_index, const float *w, bool packed, const float *bias, float *out,

@@ -583,7 +583,24 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
     float hv[KPL];
 #pragma unroll
     for (int i = 0; i < KPL; ++i) hv[i] = 0.f;
+    // the bias is requested with the first slices (it used to be a third dependent round trip behind them)
+    float bsv[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) bsv[i] = buffer_f32(bb, off[i] < 0 ? kOutside : (lane + 64 * i) * 4);
     int s = 0;
+    // sixteen slices (the dense layer's split) in flight at once: one round trip to the partials, which sit in another
+    // XCD's L2 or in memory, instead of two; the additions keep the slice order
+    for (; s + 16 <= split; s += 16) {
+        float t[KPL][16];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[i][u] = buffer_f32(pb, off[i] < 0 ? kOutside : ((s + u) * stride + off[i]) * 4);
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) hv[i] += t[i][u];
+    }
     for (; s + 8 <= split; s += 8) {
         float t[KPL][8];
 #pragma unroll
@@ -600,7 +617,7 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(const float *__rest
         for (int i = 0; i < KPL; ++i) hv[i] += buffer_f32(pb, off[i] < 0 ? kOutside : (s * stride + off[i]) * 4);
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
-        if (bias) hv[i] += buffer_f32(bb, off[i] < 0 ? kOutside : (lane + 64 * i) * 4);
+        if (bias) hv[i] += bsv[i];
         if (off[i] >= 0) h[off[i]] = hv[i];
     }
     float out = 0.f;

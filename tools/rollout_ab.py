@@ -1,7 +1,8 @@
 """Interleaved A/B of rollout switches inside ONE process (run-to-run variation between processes on a GPU box is several
 per cent, more than most of these switches move): variants alternate rollout by rollout on the same Runner.
 Usage: [PPO_EXTRA_ARGS="--agents=1024 ..."] python tools/rollout_ab.py [n_steps] [rounds]
-variants: models.FUSE_BLOCK, models.CHAIN_SPLIT, rollout.FUSE_ACT"""
+variants: models.FUSE_BLOCK, models.CHAIN_SPLIT, rollout.FUSE_ACT; PPO_AB=conv1: the first layer's two kernels
+(ppo_conv1_pool_form: LDS form / pooled out of the accumulators), everything else on"""
 import os
 import sys
 import time
@@ -32,10 +33,17 @@ if os.environ.get("PPO_AB") == "chunks":  # pieces a group's observations go up 
     variants = {f"upload chunks {c}": (1, 1, 1, c) for c in (1, 2, 4, 8)}
 if os.environ.get("PPO_AB") == "graph":  # hipGraph of a group's forward (fixed staging buffer, separate sampling launch)
     variants = {"eager": (1, 1, 1, 2, 0), "graph": (1, 1, 1, 2, 1)}
+conv1_form = None
+if os.environ.get("PPO_AB") == "conv1":
+    from ppo_amd import _lib
+    conv1_form = {"first layer: LDS form": 1, "first layer: from the accumulators": 0}
+    variants = {k: (1, 1, 1) for k in conv1_form}
 times = {k: [] for k in variants}
 for rnd in range(rounds + 1):
     for name, (blk, split, act, *rest) in variants.items():
         models.FUSE_BLOCK, models.CHAIN_SPLIT, rollout.FUSE_ACT = blk, split, act
+        if conv1_form:
+            _lib.load().ppo_conv1_pool_form(conv1_form[name])
         if rest:
             rollout.UPLOAD_CHUNKS = rest[0]
         if len(rest) > 1:
