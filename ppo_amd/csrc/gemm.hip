@@ -680,15 +680,25 @@ __global__ __launch_bounds__(256) void heads_backward_kernel(HeadsBwdArgs a)
 #pragma unroll
         for (int j = 0; j < 16; ++j)  // (the builtin moves ints: bit casts, not conversions); zeros beyond NH
             dj[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl), j));
-        for (int k = lane; k < a.H; k += 64) {
-            float w[16];
+        // four columns per lane and trip (the 256 hidden units: ONE trip), all their loads issued before the first use - the
+        // one-column loop paid a dependent round trip per 64 columns
+        for (int k0 = lane; k0 < a.H; k0 += 256) {
+            float w[4][16], gv[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) w[j] = buffer_f32(wb, j < a.NH ? (j * a.H + k) * 4 : kOutside);
-            const float gv = buffer_f32(gb, (b * a.H + k) * 4);
-            float acc = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 64 * i;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc = fmaf(dj[j], w[j], acc);
-            a.dh[b * a.H + k] = (gv > 0.f || gate_off) ? acc : 0.f;
+                for (int j = 0; j < 16; ++j) w[i][j] = buffer_f32(wb, (j < a.NH && k < a.H) ? (j * a.H + k) * 4 : kOutside);
+                gv[i] = buffer_f32(gb, k < a.H ? (b * a.H + k) * 4 : kOutside);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 64 * i;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc = fmaf(dj[j], w[i][j], acc);
+                if (k < a.H) a.dh[b * a.H + k] = (gv[i] > 0.f || gate_off) ? acc : 0.f;
+            }
         }
         return;
     }
@@ -701,10 +711,11 @@ __global__ __launch_bounds__(256) void heads_backward_kernel(HeadsBwdArgs a)
     float dW[16], dbn = 0.f, dbj = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) dW[j] = 0.f;
-    for (int b0 = part; b0 < a.B; b0 += 16 * 4) {  // four samples per trip: their loads are all issued first
-        float x[4], gv[4], d[4][16];
+    constexpr int SPT = 8;  // samples per trip: their loads are all issued first (a 256-sample minibatch: two round trips)
+    for (int b0 = part; b0 < a.B; b0 += 16 * SPT) {
+        float x[SPT], gv[SPT], d[SPT][16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SPT; ++u) {
             const int b = b0 + 16 * u;
             const bool in = b < a.B;
             x[u] = buffer_f32(hb, (in && col) ? (b * a.H + k) * 4 : kOutside);
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(256) void heads_backward_kernel(HeadsBwdArgs a)
             for (int j = 0; j < 16; ++j) d[u][j] = buffer_f32(db, (in && j < a.NH) ? (b * a.NH + j) * 4 : kOutside);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SPT; ++u) {
             const float act = a.relu_in ? fmaxf(x[u], 0.f) : x[u];
             float t = 0.f;
 #pragma unroll
