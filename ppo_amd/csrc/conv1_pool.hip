@@ -342,8 +342,9 @@ int launch_conv1(const void *in, const int32_t *in_index, const float *w, const 
 // MI355X (profiles/r04p_conv1_pool.md): back-to-back launches on a hot input are faster in the inference form (84x84: 44.0 ->
 // 35.4 us at 256 images, 22.9 -> 20.4 us at 128; training form 45.5 vs 46.4 us), but INSIDE the pipelined rollout, where the
 // observations have just been uploaded and the other env group's kernels share the chip, an env step is slower with it
-// (0.4933 vs 0.4727 ms, interleaved A/B tools/rollout_ab.py PPO_AB=conv1): a strip requests its input only two rows ahead
-// and pays the cold-memory latency row by row, where the LDS form has a whole band in flight.  So the default is the LDS
+// (0.4933 vs 0.4727 ms, interleaved A/B tools/rollout_ab.py PPO_AB=conv1; bench.py's event brackets: 51.6 vs 30.6 us for the
+// launch).  Cold input is not the reason (a ring of 690 MB of inputs: still 21.0 vs 23.3 us back to back); what differs there is
+// that 4 608 one-wave workgroups share the chip with the other group's one-workgroup-per-CU kernels.  So the default is the LDS
 // form everywhere (-1 and 1 are the same today); both kernels are bit-identical: a speed switch, not a result switch.
 static int g_form = getenv("PPO_AMD_CONV1_LDS") ? atoi(getenv("PPO_AMD_CONV1_LDS")) : -1;
 
