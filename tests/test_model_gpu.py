@@ -459,3 +459,36 @@ def test_two_workgroups_per_image_chain_launch_is_bit_identical(gold, monkeypatc
     for (p0, v0), (p1, v1) in zip(outs[0], outs[1]):
         assert torch.equal(p0, p1) and torch.equal(v0, v1)
     assert torch.equal(outs[1][0][0], outs[1][2][0]) and not torch.equal(outs[1][0][0], outs[1][1][0])
+
+
+def test_first_layer_kernel_choice_does_not_change_a_bit_of_the_network(gold):
+    """ppo_conv1_pool_form: the uint8 first layer through the LDS kernel (1) or pooled out of the MFMA accumulators (0,
+    csrc/conv1_pool.hip) - inference forward, training forward + PPO minibatch gradients (the kernel's argmax feeds the
+    first layer's weight gradient) and the parameters after an Adam step must agree bit for bit: it is a speed switch."""
+    from ppo_amd import _lib
+    g, meta = gold
+    lib = _lib.load()
+    d = {k: g[f"mb0_{k}"] for k in ("prev_state", "actions", "log_policy", "log_pac", "advantages", "returns")}
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(0, 256, size=(128, *meta["input_dims"]), dtype=np.uint8)).cuda()
+    before = lib.ppo_conv1_pool_form(-1)
+    res = {}
+    try:
+        for form in (1, 0):
+            lib.ppo_conv1_pool_form(form)
+            net = make_net(meta)
+            o = net.forward(x)
+            stats = net.ppo_minibatch(
+                torch.from_numpy(d["prev_state"]).cuda(), torch.from_numpy(d["actions"].astype(np.int32)).cuda(),
+                torch.from_numpy(d["log_pac"]).cuda(), torch.from_numpy(d["log_policy"]).cuda(),
+                torch.from_numpy(d["advantages"]).cuda(), torch.from_numpy(d["returns"]).cuda(),
+                eps_clip=meta["ppo_epsilon"], ent_coef=meta["entropy_bonus"], vf_coef=meta["ppo_vf_coef"], loss_scale=1.0)
+            grad = net.grad.clone()
+            net.adam_step()
+            torch.cuda.synchronize()
+            res[form] = (o["raw_policy"].clone(), o["value"].clone(), stats.clone(), grad, net.flat.clone())
+    finally:
+        lib.ppo_conv1_pool_form(before)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert float(res[0][3].abs().max()) > 0
