@@ -1,5 +1,5 @@
 """A few launches of the first layer's convolution + max-pool (n = 256: training form, then inference form) for a
-rocprofv3 --pmc pass (tools/_run_pmc.sh)."""
+rocprofv3 --pmc pass: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... --output-format csv -d <out> -- python3 tools/conv1_pmc.py (PPO_AMD_CONV1_LDS=0|1 picks the kernel)."""
 import os
 import sys
 
