@@ -1,6 +1,8 @@
 // First-layer convolution of the IMPALA encoder on uint8 observations (<= 4 input channels, 16 output channels),
 // fused with the 3x3 / stride 2 / pad 1 max-pool that follows it, POOLED OUT OF THE MFMA ACCUMULATORS
 // (reference: rl/impala.py:96,104-105  x = firstconv(x); x = max_pool2d(x, 3, 2, 1); input scaling rl/models.py:842-848).
+// OPT-IN (ppo_conv1_pool_form(0)): bit-identical to the LDS form and faster back to back, but an env step of the pipelined
+// rollout is slower with it - see conv1_pool_supported() below and profiles/r04p_conv1_pool.md.
 //
 // Why a second form of conv3x3_pool_kernel (conv3x3.hip) for this layer: K = 9 * 4 = 36 is nine MFMAs per 16-pixel
 // tile, so the LDS form spends most of an item outside the K loop - band staging, the pre-pool rows written to LDS,
@@ -19,8 +21,9 @@
 //  * Same K order (tap-major), same v_mfma_f32_16x16x4_f32, bias added after the chain: bit-identical to
 //    conv3x3_kernel + maxpool_fwd_kernel and to conv3x3_pool_kernel, ties and argmax included.  The argmax comes
 //    from the decomposition "first maximum of each row, then first row holding the maximum" (= first in row-major
-//    order); a window with a non-finite value or a zero maximum (whose sign is that of the FIRST zero) is redone by
-//    the reference scan pool_window_scan on the nine values.
+//    order); a pooled row with a zero maximum in one of its windows (whose sign is that of the FIRST zero) - or every
+//    row of a strip whose weights / bias are not tame (|.| > 1e30 or NaN: outputs may be non-finite) - is redone by the
+//    reference scan pool_window_scan on the nine values.
 //  * One wave per workgroup, one strip per workgroup: the hardware dispatcher balances the strips over the SIMDs;
 //    workgroup ids are read as (XCD, slot) so that the strips of one image share an L2.
 #include "common.h"
@@ -33,8 +36,9 @@
 namespace ppo {
 namespace {
 
-// DPP row shifts inside the rows of 16 lanes (one pixel tile): the value of the lane to the left / right.  `old` is left
-// undefined and bound_ctrl set, so the move folds into the consuming VALU instruction where the ISA allows it.
+// DPP row shifts inside the rows of 16 lanes (one pixel tile): the value of the lane to the left / right (zero where a
+// row of lanes ends: those lanes hold no pooled output).  One v_mov_b32_dpp each; the inference form of columns_max
+// folds the shift into v_max_f32_dpp by hand.
 __device__ __forceinline__ float from_left(float v)   // row_shr:1: lane i <- lane i - 1
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
